@@ -1,0 +1,742 @@
+// rt_host.cpp -- scene-building API, BVH construction, .obj loading, flattening, camera set-up and PNG output.
+// See include/rt_host.hpp.  Built with -ffp-contract=off: the constants derived here (boxes, plane normals, w
+// vectors, camera frame) must carry the reference's rounding, since the device compares against them exactly.
+#include "rt_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace rtamd {
+
+static const double INF = std::numeric_limits<double>::infinity();
+static const double PI = 3.14159265358979323846264338327950288;
+
+// ---- src/point3/mod.rs operators (only what construction needs) ---------------------------------------------
+static inline Point3 operator-(Point3 a) { return Point3(-a.x, -a.y, -a.z); }
+static inline Point3 operator+(Point3 a, Point3 b) { return Point3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline Point3 operator-(Point3 a, Point3 b) { return Point3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline Point3 operator*(Point3 a, double s) { return Point3(a.x * s, a.y * s, a.z * s); }
+static inline Point3 operator*(double s, Point3 a) { return Point3(s * a.x, s * a.y, s * a.z); }
+static inline Point3 operator*(Point3 a, Point3 b) { return Point3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline Point3 operator/(Point3 a, double s) { return a * (1.0 / s); }  // point3/mod.rs:137-144
+static inline double dot(Point3 u, Point3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
+static inline double length(Point3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline Point3 cross(Point3 u, Point3 v) {
+    return Point3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+static inline Point3 unit_vector(Point3 u) { return u / length(u); }
+
+// ---- src/aabb.rs --------------------------------------------------------------------------------------------
+static Range pad_to_minimums(Range r) {  // aabb.rs:71-85
+    const double DELTA = 0.0001;
+    if (r.end < r.start) throw std::runtime_error("Tried to pad reversed (and therefore empty) range");
+    if (r.end - r.start < DELTA) return Range{r.start + DELTA, r.end + DELTA};
+    return r;
+}
+AABB AABB::from_points(Point3 a, Point3 b) {  // aabb.rs:16-26
+    AABB o;
+    o.x = pad_to_minimums(a.x <= b.x ? Range{a.x, b.x} : Range{b.x, a.x});
+    o.y = pad_to_minimums(a.y <= b.y ? Range{a.y, b.y} : Range{b.y, a.y});
+    o.z = pad_to_minimums(a.z <= b.z ? Range{a.z, b.z} : Range{b.z, a.z});
+    return o;
+}
+AABB::AABB() {
+    Range r = pad_to_minimums(Range{0.0, 0.0});
+    x = y = z = r;
+}
+int AABB::longest_axis() const {  // aabb.rs:251-264
+    double xs = x.end - x.start, ys = y.end - y.start, zs = z.end - z.start;
+    if (xs > ys && xs > zs) return 0;
+    if (ys > xs && ys > zs) return 1;
+    return 2;
+}
+AABB AABB::shifted(Point3 by) const {
+    AABB o;
+    o.x = Range{x.start + by.x, x.end + by.x};
+    o.y = Range{y.start + by.y, y.end + by.y};
+    o.z = Range{z.start + by.z, z.end + by.z};
+    return o;
+}
+static Range unite(const Range& a, const Range& b) { return Range{std::fmin(a.start, b.start), std::fmax(a.end, b.end)}; }
+AABB join_aabbs(const AABB& a, const AABB& b) {  // aabb.rs:93-103
+    AABB o;
+    o.x = pad_to_minimums(unite(a.x, b.x));
+    o.y = pad_to_minimums(unite(a.y, b.y));
+    o.z = pad_to_minimums(unite(a.z, b.z));
+    return o;
+}
+
+// ---- textures / materials -----------------------------------------------------------------------------------
+std::shared_ptr<SolidColor> SolidColor::create(Color c) {
+    auto t = std::make_shared<SolidColor>();
+    t->albedo = c;
+    return t;
+}
+std::shared_ptr<CheckerTexture> CheckerTexture::from_pointers(double scale, TexturePtr even, TexturePtr odd) {
+    auto t = std::make_shared<CheckerTexture>();
+    t->inverse_scale = 1.0 / scale;
+    t->even = even;
+    t->odd = odd;
+    return t;
+}
+std::shared_ptr<CheckerTexture> CheckerTexture::from_colors(double scale, Color even, Color odd) {
+    return from_pointers(scale, SolidColor::create(even), SolidColor::create(odd));
+}
+std::shared_ptr<ImageTexture> ImageTexture::from_rgb8(const uint8_t* rgb, uint32_t w, uint32_t h) {
+    auto t = std::make_shared<ImageTexture>();
+    t->rgb.assign(rgb, rgb + (size_t)3 * w * h);
+    t->width = w;
+    t->height = h;
+    return t;
+}
+static bool read_ppm(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string magic;
+    f >> magic;
+    if (magic != "P6") return false;
+    auto next_int = [&](long& v) -> bool {
+        for (;;) {
+            int c = f.peek();
+            if (c == '#') { std::string skip; std::getline(f, skip); continue; }
+            if (c == ' ' || c == '\n' || c == '\r' || c == '\t') { f.get(); continue; }
+            break;
+        }
+        return (bool)(f >> v);
+    };
+    long W, H, M;
+    if (!next_int(W) || !next_int(H) || !next_int(M)) return false;
+    if (W <= 0 || H <= 0 || M != 255 || W > 65536 || H > 65536) return false;
+    f.get();  // the single whitespace after maxval
+    rgb.resize((size_t)3 * W * H);
+    f.read((char*)rgb.data(), (std::streamsize)rgb.size());
+    if ((size_t)f.gcount() != rgb.size()) return false;
+    w = (uint32_t)W;
+    h = (uint32_t)H;
+    return true;
+}
+TexturePtr ImageTexture::new_or_fallback(const std::string& path) {
+    std::vector<uint8_t> rgb;
+    uint32_t w = 0, h = 0;
+    if (read_ppm(path, rgb, w, h)) return from_rgb8(rgb.data(), w, h);
+    std::fprintf(stderr, "Could not load the image texture %s. Falling back to default.\n", path.c_str());
+    return CheckerTexture::from_colors(2.0, Color(1.0, 0.0, 0.862745098039), Color(0.00392156862745, 0.0, 0.00392156862745));
+}
+PerlinNoise create_perlin_noise(const double* d) {
+    PerlinNoise n;
+    for (int i = 0; i < 256; ++i) {
+        n.random_vectors[i][0] = d[3 * i];
+        n.random_vectors[i][1] = d[3 * i + 1];
+        n.random_vectors[i][2] = d[3 * i + 2];
+        n.x_perm[i] = n.y_perm[i] = n.z_perm[i] = (uint32_t)i;
+    }
+    return n;
+}
+std::shared_ptr<PerlinNoiseTexture> PerlinNoiseTexture::create(const PerlinNoise& n, double scale) {
+    auto t = std::make_shared<PerlinNoiseTexture>();
+    t->perlin_noise = n;
+    t->scale = scale;
+    return t;
+}
+std::shared_ptr<Lambertian> Lambertian::from_color(Color c) { return from_texture(SolidColor::create(c)); }
+std::shared_ptr<Lambertian> Lambertian::from_texture(TexturePtr t) {
+    auto m = std::make_shared<Lambertian>();
+    m->texture = t;
+    return m;
+}
+std::shared_ptr<Metal> metal(Color albedo, double fuzz) {
+    auto m = std::make_shared<Metal>();
+    m->albedo = albedo;
+    m->fuzz = fuzz;
+    return m;
+}
+std::shared_ptr<Dielectric> dielectric(double ri) {
+    auto m = std::make_shared<Dielectric>();
+    m->refraction_index = ri;
+    return m;
+}
+std::shared_ptr<DiffuseLight> DiffuseLight::from_color(Color c) { return from_texture(SolidColor::create(c)); }
+std::shared_ptr<DiffuseLight> DiffuseLight::from_texture(TexturePtr t) {
+    auto m = std::make_shared<DiffuseLight>();
+    m->texture = t;
+    return m;
+}
+
+// ---- primitives ---------------------------------------------------------------------------------------------
+Sphere::Sphere(Point3 c, double r, MaterialPtr m) : center(c), radius(std::fmax(r, 0.0)), material(m) {
+    Point3 rv(r, r, r);
+    bbox_ = AABB::from_points(c - rv, c + rv);  // sphere.rs:24-29
+}
+static void derive_plane(Point3 q, Vector3 u, Vector3 v, Vector3& normal, double& d, Vector3& w) {
+    Vector3 n = cross(u, v);  // parallelogram.rs:43-46, triangle.rs:42-45
+    normal = unit_vector(n);
+    d = dot(normal, q);
+    w = n / dot(n, n);
+}
+Parallelogram::Parallelogram(Point3 q_, Vector3 u_, Vector3 v_, MaterialPtr m) : q(q_), u(u_), v(v_), material(m) {
+    AABB b0 = AABB::from_points(q, q + u + v);  // parallelogram.rs:31-37
+    AABB b1 = AABB::from_points(q + u, q + v);
+    bbox_ = join_aabbs(b0, b1);
+    derive_plane(q, u, v, normal, d, w);
+}
+Triangle::Triangle(Point3 q_, Vector3 u_, Vector3 v_, MaterialPtr m) : q(q_), u(u_), v(v_), material(m) {
+    AABB b0 = AABB::from_points(q, q + u);  // triangle.rs:30-36
+    AABB b1 = AABB::from_points(q, q + v);
+    bbox_ = join_aabbs(b0, b1);
+    derive_plane(q, u, v, normal, d, w);
+}
+std::shared_ptr<Triangle> Triangle::from_vertex_locations(Point3 v1, Point3 v2, Point3 v3, MaterialPtr m) {
+    return std::make_shared<Triangle>(v1, v2 - v1, v3 - v1, m);  // triangle.rs:58-87
+}
+std::shared_ptr<Quadric> make_quadric(Point3 p1, Point3 p2, Point3 p3, double j, MaterialPtr m, AABB box) {
+    auto q = std::make_shared<Quadric>();
+    q->p1 = p1; q->p2 = p2; q->p3 = p3; q->j = j; q->material = m; q->bbox_ = box;
+    return q;
+}
+std::shared_ptr<Quadric> y_cylinder(Point3 c, double r, MaterialPtr m) {
+    Point3 rv(r, r, r);
+    return make_quadric(Point3(1.0, 0.0, 1.0), Point3(), c * Point3(-2.0, 0.0, -2.0), -r * r + c.x * c.x + c.z * c.z, m,
+                        AABB::from_points(c - rv, c + rv));
+}
+std::shared_ptr<Quadric> quadric_sphere(Point3 c, double r, MaterialPtr m) {
+    Point3 rv(r, r, r);
+    return make_quadric(Point3(1.0, 1.0, 1.0), Point3(), -2.0 * c, -r * r + dot(c, c), m, AABB::from_points(c - rv, c + rv));
+}
+std::shared_ptr<Quadric> y_cone(Point3 c, Point3 off, MaterialPtr m) {
+    Point3 ind(1.0, -1.0, 1.0);
+    return make_quadric(ind, Point3(), (-2.0 * ind) * c, dot(c * ind, c), m, AABB::from_points(c - off, c + off));
+}
+
+// ---- collections --------------------------------------------------------------------------------------------
+void HittableList::add_pointer(HittablePtr o) {  // hittable_list.rs:32-40
+    bounding_box = join_aabbs(bounding_box, o->bounding_box());
+    objects.push_back(o);
+}
+std::shared_ptr<HittableSlice> HittableList::to_hittable_slice() const { return HittableSlice::from_hittable_list(*this); }
+std::shared_ptr<BVHNode> HittableList::to_bvh_node() const { return BVHNode::from_hittable_list(*this); }
+
+namespace {
+struct SliceAccess : HittableSlice {
+    void set_box(const AABB& b) { bbox_ = b; }
+};
+}  // namespace
+std::shared_ptr<HittableSlice> HittableSlice::from_hittable_list(const HittableList& l) {
+    auto s = std::make_shared<SliceAccess>();
+    s->objects = l.objects;
+    s->set_box(l.bounding_box);
+    return s;
+}
+HittableList create_box(Point3 a, Point3 b, MaterialPtr m) {  // parallelogram.rs:146-195
+    HittableList sides;
+    Point3 mn(std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z));
+    Point3 mx(std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z));
+    Point3 dx(mx.x - mn.x, 0.0, 0.0), dy(0.0, mx.y - mn.y, 0.0), dz(0.0, 0.0, mx.z - mn.z);
+    sides.add(std::make_shared<Parallelogram>(Point3(mn.x, mn.y, mx.z), dx, dy, m));
+    sides.add(std::make_shared<Parallelogram>(Point3(mx.x, mn.y, mx.z), -dz, dy, m));
+    sides.add(std::make_shared<Parallelogram>(Point3(mx.x, mn.y, mn.z), -dx, dy, m));
+    sides.add(std::make_shared<Parallelogram>(Point3(mn.x, mn.y, mn.z), dz, dy, m));
+    sides.add(std::make_shared<Parallelogram>(Point3(mn.x, mx.y, mx.z), dx, -dz, m));
+    sides.add(std::make_shared<Parallelogram>(Point3(mn.x, mn.y, mn.z), dx, dz, m));
+    return sides;
+}
+
+static inline int64_t total_order_key(double x) {  // f64::total_cmp
+    int64_t b;
+    std::memcpy(&b, &x, 8);
+    b ^= (int64_t)((uint64_t)(b >> 63) >> 1);
+    return b;
+}
+BVHNode::BVHNode(std::vector<HittablePtr> objs) {  // bvh.rs:87-138
+    AABB box;
+    for (auto& o : objs) box = join_aabbs(box, o->bounding_box());
+    int axis = box.longest_axis();
+    const size_t THRESHOLD = 16;
+    if (objs.size() <= THRESHOLD) {
+        HittableList l;
+        for (auto& o : objs) l.add_pointer(o);
+        leaf = true;
+        objects = HittableSlice::from_hittable_list(l);
+        bbox_ = l.bounding_box;
+    } else {
+        // Vec::sort_by is stable; the upper half (split_off(mid)) becomes `left` and is visited first.
+        std::stable_sort(objs.begin(), objs.end(), [axis](const HittablePtr& a, const HittablePtr& b) {
+            return total_order_key(a->bounding_box().axis_interval(axis).start) <
+                   total_order_key(b->bounding_box().axis_interval(axis).start);
+        });
+        size_t mid = objs.size() / 2;
+        std::vector<HittablePtr> upper(objs.begin() + (std::ptrdiff_t)mid, objs.end());
+        objs.resize(mid);
+        left = std::make_shared<BVHNode>(std::move(upper));
+        right = std::make_shared<BVHNode>(std::move(objs));
+        bbox_ = box;
+    }
+}
+std::shared_ptr<BVHNode> BVHNode::from_hittable_list(const HittableList& l) { return std::make_shared<BVHNode>(l.objects); }
+std::shared_ptr<BVHNode> BVHNode::from_vec(std::vector<HittablePtr> o) { return std::make_shared<BVHNode>(std::move(o)); }
+
+Translate::Translate(HittablePtr o, Vector3 off) : object(o), offset(off) { bbox_ = o->bounding_box().shifted(off); }
+RotateY::RotateY(HittablePtr o, double deg) : object(o) {  // hittable/mod.rs:143-188
+    double radians = deg * (PI / 180.0);
+    sin_theta = std::sin(radians);
+    cos_theta = std::cos(radians);
+    const AABB& bb = o->bounding_box();
+    double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
+    for (int ii = 0; ii < 2; ++ii)
+        for (int jj = 0; jj < 2; ++jj)
+            for (int kk = 0; kk < 2; ++kk) {
+                double i = ii, j = jj, k = kk;
+                double x = i * bb.x.end + (1.0 - i) * bb.x.start;
+                double y = j * bb.y.end + (1.0 - j) * bb.y.start;
+                double z = k * bb.z.end + (1.0 - k) * bb.z.start;
+                double t[3] = {cos_theta * x + sin_theta * z, y, -sin_theta * x + cos_theta * z};
+                // As the reference computes it (:174-177): only x and y, and the maximum also takes `min`.  The box
+                // is never tested in the reference's scenes (rotated instances sit in top-level slices); it is kept
+                // so that enclosing boxes come out the same.
+                for (int c = 0; c < 2; ++c) {
+                    mn[c] = std::fmin(mn[c], t[c]);
+                    mx[c] = std::fmin(mx[c], t[c]);
+                }
+            }
+    bbox_ = AABB::from_points(Point3(mn[0], mn[1], mn[2]), Point3(mx[0], mx[1], mx[2]));
+}
+ConstantMedium::ConstantMedium(HittablePtr b, double density, TexturePtr tex) : boundary(b), neg_inv_density(-1.0 / density) {
+    auto iso = std::make_shared<Isotropic>();
+    iso->texture = tex;
+    phase_function = iso;
+    bbox_ = b->bounding_box();
+}
+std::shared_ptr<ConstantMedium> ConstantMedium::from_color(HittablePtr b, double density, Color c) {
+    return std::make_shared<ConstantMedium>(b, density, SolidColor::create(c));
+}
+
+// ---- load_obj.rs -------------------------------------------------------------------------------------------
+std::shared_ptr<BVHNode> load_model(const std::string& path, double scale, MaterialPtr material) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("load_model: cannot open " + path);
+    std::vector<Point3> verts;
+    std::vector<std::vector<size_t>> faces;
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream ls(line);
+        std::string first;
+        if (!(ls >> first)) continue;
+        if (first == "v") {
+            std::vector<double> c;
+            std::string tok;
+            while (ls >> tok) {
+                char* endp = nullptr;
+                double v = std::strtod(tok.c_str(), &endp);
+                if (endp == tok.c_str() || *endp) throw std::runtime_error("load_model: bad coordinate '" + tok + "'");
+                c.push_back(v);
+            }
+            if (c.size() != 3) throw std::runtime_error("unable to parse non 3d coordinates");
+            verts.push_back(Point3(c[0], c[1], c[2]));
+        } else if (first == "f") {
+            std::vector<size_t> vs;
+            std::string tok;
+            while (ls >> tok) {
+                std::string head = tok.substr(0, tok.find('/'));
+                char* endp = nullptr;
+                long long i = std::strtoll(head.c_str(), &endp, 10);
+                if (endp == head.c_str() || *endp || i < 1) throw std::runtime_error("load_model: bad face index '" + tok + "'");
+                vs.push_back((size_t)i - 1);
+            }
+            faces.push_back(vs);
+        } else if (first == "vn" || first == "vt" || first == "#" || first == "s" || first == "o" || first == "vp" ||
+                   first == "usemtl" || first == "mtllib" || first == "g") {
+            // ignored (load_obj.rs:55-73)
+        } else {
+            throw std::runtime_error("Unexpected line in `.obj` file. Line is: " + line);
+        }
+    }
+    std::vector<HittablePtr> triangles;
+    for (auto& face : faces) {
+        if (face.empty()) continue;
+        for (size_t ix : face)
+            if (ix >= verts.size()) throw std::runtime_error("load_model: face index out of range");
+        auto scaled = [&](size_t ix) { return Point3(scale * verts[ix].x, scale * verts[ix].y, scale * verts[ix].z); };
+        Point3 v1 = scaled(face[0]);
+        for (size_t k = 1; k + 1 < face.size(); ++k)  // fan triangulation, load_obj.rs:88-106
+            triangles.push_back(Triangle::from_vertex_locations(v1, scaled(face[k]), scaled(face[k + 1]), material));
+    }
+    return BVHNode::from_vec(std::move(triangles));
+}
+
+// ---- flatten -----------------------------------------------------------------------------------------------
+class Flattener {
+public:
+    FlatScene out;
+    std::map<const Material*, uint32_t> mat_ids;
+    std::map<const Texture*, uint32_t> tex_ids;
+    std::map<const Hittable*, uint32_t> prim_ids;
+    std::vector<rt_xform_op> chain_stack;
+    std::map<std::vector<std::pair<uint32_t, std::vector<double>>>, uint32_t> chain_ids;
+    uint32_t level = 0;
+    bool in_medium = false;
+
+    Flattener() {
+        rt_chain c0 = {0, 0};
+        out.chains.push_back(c0);
+        chain_ids[{}] = 0;
+    }
+    uint32_t prim_id(const Hittable* h) {  // first visit wins, in depth-first order
+        auto it = prim_ids.find(h);
+        if (it != prim_ids.end()) return it->second;
+        uint32_t id = out.n_prim_ids++;
+        prim_ids[h] = id;
+        return id;
+    }
+    uint32_t texture(const Texture* t) {
+        auto it = tex_ids.find(t);
+        if (it != tex_ids.end()) return it->second;
+        rt_texture r;
+        std::memset(&r, 0, sizeof r);
+        r.kind = t->kind();
+        switch (t->kind()) {
+            case RT_TEX_SOLID: {
+                auto* s = static_cast<const SolidColor*>(t);
+                r.color[0] = s->albedo.x; r.color[1] = s->albedo.y; r.color[2] = s->albedo.z;
+                break;
+            }
+            case RT_TEX_CHECKER: {
+                auto* c = static_cast<const CheckerTexture*>(t);
+                r.a = texture(c->even.get());  // children first: a parent's index is above its children's
+                r.b = texture(c->odd.get());
+                r.scale = c->inverse_scale;
+                break;
+            }
+            case RT_TEX_IMAGE: {
+                auto* im = static_cast<const ImageTexture*>(t);
+                FlatScene::Image fi;
+                fi.rgb = im->rgb; fi.w = im->width; fi.h = im->height;
+                r.a = (uint32_t)out.images.size();
+                out.images.push_back(std::move(fi));
+                break;
+            }
+            case RT_TEX_PERLIN: {
+                auto* p = static_cast<const PerlinNoiseTexture*>(t);
+                FlatScene::Perlin fp;
+                for (int i = 0; i < 256; ++i)
+                    for (int k = 0; k < 3; ++k) fp.vec.push_back(p->perlin_noise.random_vectors[i][k]);
+                fp.perm.insert(fp.perm.end(), p->perlin_noise.x_perm, p->perlin_noise.x_perm + 256);
+                fp.perm.insert(fp.perm.end(), p->perlin_noise.y_perm, p->perlin_noise.y_perm + 256);
+                fp.perm.insert(fp.perm.end(), p->perlin_noise.z_perm, p->perlin_noise.z_perm + 256);
+                r.a = (uint32_t)out.perlins.size();
+                r.scale = p->scale;
+                out.perlins.push_back(std::move(fp));
+                break;
+            }
+        }
+        uint32_t id = (uint32_t)out.textures.size();
+        out.textures.push_back(r);
+        tex_ids[t] = id;
+        return id;
+    }
+    uint32_t material(const Material* m) {
+        auto it = mat_ids.find(m);
+        if (it != mat_ids.end()) return it->second;
+        rt_material r;
+        std::memset(&r, 0, sizeof r);
+        r.kind = m->kind();
+        switch (m->kind()) {
+            case RT_MAT_LAMBERTIAN: r.texture = texture(static_cast<const Lambertian*>(m)->texture.get()); break;
+            case RT_MAT_METAL: {
+                auto* mt = static_cast<const Metal*>(m);
+                r.albedo[0] = mt->albedo.x; r.albedo[1] = mt->albedo.y; r.albedo[2] = mt->albedo.z;
+                r.param = mt->fuzz;
+                break;
+            }
+            case RT_MAT_DIELECTRIC: r.param = static_cast<const Dielectric*>(m)->refraction_index; break;
+            case RT_MAT_DIFFUSE_LIGHT: r.texture = texture(static_cast<const DiffuseLight*>(m)->texture.get()); break;
+            case RT_MAT_ISOTROPIC: r.texture = texture(static_cast<const Isotropic*>(m)->texture.get()); break;
+        }
+        uint32_t id = (uint32_t)out.materials.size();
+        out.materials.push_back(r);
+        mat_ids[m] = id;
+        return id;
+    }
+    uint32_t chain() {
+        std::vector<std::pair<uint32_t, std::vector<double>>> key;
+        for (auto& op : chain_stack) key.push_back({op.kind, {op.v[0], op.v[1], op.v[2]}});
+        auto it = chain_ids.find(key);
+        if (it != chain_ids.end()) return it->second;
+        if (out.chains.size() >= 65535) throw std::runtime_error("flatten: too many distinct instance chains");
+        rt_chain c;
+        c.first_op = (uint32_t)out.ops.size();
+        c.n_ops = (uint32_t)chain_stack.size();
+        out.ops.insert(out.ops.end(), chain_stack.begin(), chain_stack.end());
+        uint32_t id = (uint32_t)out.chains.size();
+        out.chains.push_back(c);
+        chain_ids[key] = id;
+        return id;
+    }
+    void emit_run(rt_node_kind kind, uint32_t index) {
+        uint32_t ch = chain();
+        if (!out.nodes.empty()) {
+            rt_node& last = out.nodes.back();
+            if (last.kind == kind && last.level == level && last.chain == ch && last.first + last.count == index) {
+                last.count++;
+                return;
+            }
+        }
+        rt_node n;
+        n.kind = (uint8_t)kind;
+        n.level = (uint8_t)level;
+        n.chain = (uint16_t)ch;
+        n.first = index;
+        n.count = 1;
+        n.skip = (uint32_t)out.nodes.size() + 1u;
+        out.nodes.push_back(n);
+    }
+    size_t open(rt_node_kind kind, uint32_t first) {
+        if (level + 2u > RT_MAX_LEVELS) throw std::runtime_error("flatten: BVH/medium nesting deeper than RT_MAX_LEVELS");
+        rt_node n;
+        n.kind = (uint8_t)kind;
+        n.level = (uint8_t)level;
+        n.chain = (uint16_t)chain();
+        n.first = first;
+        n.count = 0;
+        n.skip = 0;
+        out.nodes.push_back(n);
+        level++;
+        return out.nodes.size() - 1;
+    }
+    void close(size_t at) {
+        level--;
+        out.nodes[at].skip = (uint32_t)out.nodes.size();
+    }
+};
+
+void Sphere::flatten(Flattener& f) const {
+    uint32_t k = (uint32_t)f.out.sphere_mat.size();
+    double rec[4] = {center.x, center.y, center.z, radius};
+    f.out.spheres.insert(f.out.spheres.end(), rec, rec + 4);
+    f.out.sphere_mat.push_back(f.material(material.get()));
+    f.out.sphere_id.push_back(f.prim_id(this));
+    f.emit_run(RT_NODE_SPHERES, k);
+}
+static void planar_record(std::vector<double>& dst, const Vector3& n, double d, const Vector3& q, const Vector3& u,
+                          const Vector3& v, const Vector3& w) {
+    double rec[16] = {n.x, n.y, n.z, d, q.x, q.y, q.z, u.x, u.y, u.z, v.x, v.y, v.z, w.x, w.y, w.z};
+    dst.insert(dst.end(), rec, rec + 16);
+}
+void Parallelogram::flatten(Flattener& f) const {
+    uint32_t k = (uint32_t)f.out.quad_mat.size();
+    planar_record(f.out.quads, normal, d, q, u, v, w);
+    f.out.quad_mat.push_back(f.material(material.get()));
+    f.out.quad_id.push_back(f.prim_id(this));
+    f.emit_run(RT_NODE_QUADS, k);
+}
+void Triangle::flatten(Flattener& f) const {
+    uint32_t k = (uint32_t)f.out.tri_mat.size();
+    planar_record(f.out.triangles, normal, d, q, u, v, w);
+    f.out.tri_mat.push_back(f.material(material.get()));
+    f.out.tri_id.push_back(f.prim_id(this));
+    f.emit_run(RT_NODE_TRIANGLES, k);
+}
+void Quadric::flatten(Flattener& f) const {
+    uint32_t k = (uint32_t)f.out.quadric_mat.size();
+    double rec[10] = {p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, p3.x, p3.y, p3.z, j};
+    f.out.quadrics.insert(f.out.quadrics.end(), rec, rec + 10);
+    f.out.quadric_mat.push_back(f.material(material.get()));
+    f.out.quadric_id.push_back(f.prim_id(this));
+    f.emit_run(RT_NODE_QUADRICS, k);
+}
+void HittableSlice::flatten(Flattener& f) const {
+    for (auto& o : objects) o->flatten(f);  // list order = visit order (hittable_list.rs:93-99)
+}
+void BVHNode::flatten(Flattener& f) const {
+    uint32_t box = (uint32_t)(f.out.boxes.size() / 6);
+    const AABB& b = bbox_;
+    double rec[6] = {b.x.start, b.x.end, b.y.start, b.y.end, b.z.start, b.z.end};
+    f.out.boxes.insert(f.out.boxes.end(), rec, rec + 6);
+    size_t at = f.open(RT_NODE_BVH, box);
+    if (leaf) {
+        objects->flatten(f);
+    } else {
+        left->flatten(f);  // bvh.rs:50-57: left first, then right
+        right->flatten(f);
+    }
+    f.close(at);
+}
+void Translate::flatten(Flattener& f) const {
+    rt_xform_op op;
+    std::memset(&op, 0, sizeof op);
+    op.kind = RT_XF_TRANSLATE;
+    op.v[0] = offset.x; op.v[1] = offset.y; op.v[2] = offset.z;
+    f.chain_stack.push_back(op);
+    object->flatten(f);
+    f.chain_stack.pop_back();
+}
+void RotateY::flatten(Flattener& f) const {
+    rt_xform_op op;
+    std::memset(&op, 0, sizeof op);
+    op.kind = RT_XF_ROTATE_Y;
+    op.v[0] = sin_theta; op.v[1] = cos_theta;
+    f.chain_stack.push_back(op);
+    object->flatten(f);
+    f.chain_stack.pop_back();
+}
+void ConstantMedium::flatten(Flattener& f) const {
+    if (f.in_medium) throw std::runtime_error("flatten: a ConstantMedium inside a medium's boundary is not supported");
+    rt_medium m;
+    m.neg_inv_density = neg_inv_density;
+    m.material = f.material(phase_function.get());
+    m.prim_id = f.prim_id(this);
+    uint32_t k = (uint32_t)f.out.media.size();
+    f.out.media.push_back(m);
+    size_t at = f.open(RT_NODE_MEDIUM, k);
+    f.in_medium = true;
+    boundary->flatten(f);
+    f.in_medium = false;
+    f.close(at);
+}
+
+FlatScene flatten(const Hittable& world) {
+    Flattener f;
+    world.flatten(f);
+    return std::move(f.out);
+}
+
+rt_scene* FlatScene::commit(int device) const {
+    rt_scene* s = rt_scene_create();
+    if (!s) return nullptr;
+    bool ok = rt_scene_set_materials(s, materials.data(), (uint32_t)materials.size()) == RT_OK &&
+              rt_scene_set_textures(s, textures.data(), (uint32_t)textures.size()) == RT_OK;
+    for (size_t i = 0; ok && i < images.size(); ++i)
+        ok = rt_scene_set_image(s, (uint32_t)i, images[i].rgb.data(), images[i].w, images[i].h) == RT_OK;
+    for (size_t i = 0; ok && i < perlins.size(); ++i)
+        ok = rt_scene_set_perlin(s, (uint32_t)i, perlins[i].vec.data(), perlins[i].perm.data()) == RT_OK;
+    ok = ok && rt_scene_set_spheres(s, spheres.data(), sphere_mat.data(), sphere_id.data(), (uint32_t)sphere_mat.size()) == RT_OK;
+    ok = ok && rt_scene_set_quads(s, quads.data(), quad_mat.data(), quad_id.data(), (uint32_t)quad_mat.size()) == RT_OK;
+    ok = ok && rt_scene_set_triangles(s, triangles.data(), tri_mat.data(), tri_id.data(), (uint32_t)tri_mat.size()) == RT_OK;
+    ok = ok && rt_scene_set_quadrics(s, quadrics.data(), quadric_mat.data(), quadric_id.data(), (uint32_t)quadric_mat.size()) == RT_OK;
+    ok = ok && rt_scene_set_media(s, media.data(), (uint32_t)media.size()) == RT_OK;
+    ok = ok && rt_scene_set_xforms(s, ops.data(), (uint32_t)ops.size(), chains.data(), (uint32_t)chains.size()) == RT_OK;
+    ok = ok && rt_scene_set_nodes(s, nodes.data(), (uint32_t)nodes.size(), boxes.data(), (uint32_t)(boxes.size() / 6)) == RT_OK;
+    ok = ok && rt_scene_commit(s, device) == RT_OK;
+    if (!ok) {
+        rt_scene_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+// ---- camera ------------------------------------------------------------------------------------------------
+static void st3(double* o, Point3 p) { o[0] = p.x; o[1] = p.y; o[2] = p.z; }
+Camera Camera::create(double aspect_ratio, uint32_t image_width, ImageQuality q, double vfov, ThinLens lens,
+                      CameraPosition pos, Color background) {  // camera.rs:80-143
+    Camera c;
+    std::memset(&c.cam, 0, sizeof c.cam);
+    uint32_t hh = (uint32_t)((double)image_width / aspect_ratio);
+    uint32_t image_height = hh < 1 ? 1 : hh;
+    double theta = vfov * (PI / 180.0);
+    double h = std::tan(theta * 0.5);
+    double viewport_height = 2.0 * h * lens.focus_distance;
+    double viewport_width = viewport_height * ((double)image_width / (double)image_height);
+    Vector3 w = unit_vector(pos.look_from - pos.look_at);
+    Vector3 u = unit_vector(cross(pos.view_up, w));
+    Vector3 v = unit_vector(cross(w, u));
+    Vector3 viewport_u = u * viewport_width;
+    Vector3 viewport_v = v * (-viewport_height);
+    Vector3 du = viewport_u / (double)image_width;
+    Vector3 dv = viewport_v / (double)image_height;
+    Point3 upper_left = pos.look_from - w * lens.focus_distance - viewport_u * 0.5 - viewport_v * 0.5;
+    Point3 pixel00 = upper_left + (du + dv) * 0.5;
+    double defocus_radius = lens.focus_distance * std::tan((lens.defocus_angle * 0.5) * (PI / 180.0));
+    c.cam.width = image_width;
+    c.cam.height = image_height;
+    st3(c.cam.pixel00, pixel00);
+    st3(c.cam.delta_u, du);
+    st3(c.cam.delta_v, dv);
+    st3(c.cam.center, pos.look_from);
+    c.cam.defocus_angle = lens.defocus_angle;
+    st3(c.cam.disk_u, u * defocus_radius);
+    st3(c.cam.disk_v, v * defocus_radius);
+    c.samples_per_pixel = q.samples_per_pixel;
+    c.max_depth = q.max_depth;
+    c.background_color = background;
+    return c;
+}
+
+int Camera::render(const Hittable& world, rt_stats* stats) const {
+    FlatScene flat;
+    try {
+        flat = flatten(world);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "flatten failed: %s\n", e.what());
+        return RT_ERR_INVALID;
+    }
+    rt_scene* s = flat.commit(device);
+    if (!s) {
+        std::fprintf(stderr, "scene commit failed: %s\n", rt_last_error());
+        return RT_ERR_DEVICE;
+    }
+    rt_render_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.spp_begin = 0;
+    o.spp_count = samples_per_pixel;
+    o.max_depth = max_depth;
+    o.seed = seed;
+    o.background[0] = background_color.x; o.background[1] = background_color.y; o.background[2] = background_color.z;
+    size_t npix = (size_t)cam.width * cam.height;
+    std::vector<double> film(3 * npix);
+    std::vector<uint8_t> rgb(3 * npix);
+    int rc = rt_render(s, &cam, &o, film.data(), stats);
+    if (rc == RT_OK) rc = rt_tonemap_rgb8(s, film.data(), cam.width, cam.height, samples_per_pixel, rgb.data());
+    if (rc != RT_OK) std::fprintf(stderr, "render failed: %s\n", rt_last_error());
+    rt_scene_destroy(s);
+    if (rc == RT_OK && !write_png(output_path, rgb.data(), cam.width, cam.height)) {
+        std::fprintf(stderr, "could not write %s\n", output_path.c_str());
+        return RT_ERR_INVALID;
+    }
+    return rc;
+}
+
+// ---- PNG ---------------------------------------------------------------------------------------------------
+static void be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+static void chunk(std::vector<uint8_t>& out, const char* tag, const std::vector<uint8_t>& data) {
+    be32(out, (uint32_t)data.size());
+    std::vector<uint8_t> body(tag, tag + 4);
+    body.insert(body.end(), data.begin(), data.end());
+    out.insert(out.end(), body.begin(), body.end());
+    be32(out, (uint32_t)crc32(0L, body.data(), (uInt)body.size()));
+}
+bool write_png(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h) {
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (3 * w + 1));
+    for (uint32_t y = 0; y < h; ++y) {
+        raw.push_back(0);  // filter: none
+        raw.insert(raw.end(), rgb + (size_t)3 * w * y, rgb + (size_t)3 * w * (y + 1));
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    comp.resize(clen);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, w);
+    be32(ihdr, h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(out, "IHDR", ihdr);
+    chunk(out, "IDAT", comp);
+    chunk(out, "IEND", {});
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    if (!fp) return false;
+    bool ok = std::fwrite(out.data(), 1, out.size(), fp) == out.size();
+    ok = (std::fclose(fp) == 0) && ok;
+    return ok;
+}
+
+}  // namespace rtamd

@@ -1,0 +1,643 @@
+// rt_core.h -- per-lane device functions of the path tracer: vector math, the counter-based generator, the
+// flattened-tree walk with the reference's interval semantics, hit-record reconstruction, textures and materials.
+//
+// Everything is f64 and keeps the reference's operation order (citations are reference file:line); the file
+// must be compiled with -ffp-contract=off so that no multiply-add pair is fused.  Functions are
+// __host__ __device__ only so that tests can single-step the same code on the CPU; the library itself never
+// runs them on the host.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+
+#define RT_HD __host__ __device__ __forceinline__
+
+namespace rt {
+
+#define RT_INF (__builtin_inf())
+#define RT_PI 3.14159265358979323846264338327950288
+
+// hit reference: kind in the top 3 bits, index in the type's array below
+#define RT_REF_KIND_SHIFT 29
+#define RT_REF_INDEX_MASK 0x1FFFFFFFu
+RT_HD uint32_t make_ref(uint32_t kind, uint32_t index) { return (kind << RT_REF_KIND_SHIFT) | index; }
+
+struct V3 {
+    double x, y, z;
+};
+// src/point3/mod.rs:70-170
+RT_HD V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_HD V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+RT_HD V3 operator*(double s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+RT_HD V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD V3 operator/(V3 a, double s) { return a * (1.0 / s); }  // :137-144: division is a multiply by 1/s
+RT_HD double len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }  // :175-177
+RT_HD double dot(V3 u, V3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }  // :183-191
+RT_HD V3 cross(V3 u, V3 v) {  // :194-200
+    return mk(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+RT_HD V3 rotate_y(V3 p, double c, double s) { return mk(c * p.x - s * p.z, p.y, s * p.x + c * p.z); }  // :203-209
+RT_HD V3 unit(V3 u) { return u / sqrt(len2(u)); }  // :221-223
+RT_HD bool near_zero(V3 a) { return fabs(a.x) < 1e-8 && fabs(a.y) < 1e-8 && fabs(a.z) < 1e-8; }  // :214-217
+RT_HD V3 reflect(V3 v, V3 n) { return v - (2.0 * dot(v, n)) * n; }  // :279-281
+RT_HD V3 refract(V3 uv, V3 n, double eta) {  // :284-293
+    double cos_theta = fmin(dot(-uv, n), 1.0);
+    V3 perp = (uv + n * cos_theta) * eta;
+    V3 par = (-n) * sqrt(fabs(1.0 - len2(perp)));
+    return perp + par;
+}
+RT_HD V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Counter-based generator: Philox4x32-10 keyed by the render seed, counter = (pixel, sample, draw block, stream).
+// Draw d uses block d >> 1: words {0,1} when d is even, {2,3} when odd; 52 bits become a double in [0,1) the way
+// rand 0.9's UniformFloat<f64> does.  Stands in for the rand::random_range call sites (camera.rs:503-504,
+// point3/mod.rs:231-233,266-267, material.rs:139, constant_medium.rs:72).
+struct Rng {
+    uint32_t k0, k1, pixel, sample, ctr;
+    uint32_t blk;   // block held in w[], 0xFFFFFFFF when none
+    uint32_t w[4];
+};
+RT_HD Rng rng_make(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t ctr) {
+    Rng r;
+    r.k0 = (uint32_t)seed;
+    r.k1 = (uint32_t)(seed >> 32);
+    r.pixel = pixel;
+    r.sample = sample;
+    r.ctr = ctr;
+    r.blk = 0xFFFFFFFFu;
+    r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+    return r;
+}
+RT_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+RT_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = mulhi32(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = mulhi32(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0;
+        uint32_t n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+RT_HD double rng_next01(Rng& r) {
+    uint32_t b = r.ctr >> 1;
+    if (b != r.blk) {
+        r.w[0] = r.pixel; r.w[1] = r.sample; r.w[2] = b; r.w[3] = 0u;
+        philox4x32_10(r.w, r.k0, r.k1);
+        r.blk = b;
+    }
+    uint64_t bits = (r.ctr & 1u) ? (((uint64_t)r.w[3] << 32) | r.w[2]) : (((uint64_t)r.w[1] << 32) | r.w[0]);
+    r.ctr++;
+    return (double)(bits >> 12) * (1.0 / 4503599627370496.0);
+}
+RT_HD double rng_range(Rng& r, double lo, double hi) { return rng_next01(r) * (hi - lo) + lo; }
+RT_HD V3 random_unit_vector(Rng& r) {  // point3/mod.rs:229-250
+    for (;;) {
+        double x = rng_range(r, -1.0, 1.0);
+        double y = rng_range(r, -1.0, 1.0);
+        double z = rng_range(r, -1.0, 1.0);
+        V3 p = mk(x, y, z);
+        if (len2(p) < 1.0) return unit(p);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Scene as the kernels see it: per-type arrays of packed f64 records plus the flattened tree.
+struct DScene {
+    const rt_node* nodes;
+    uint32_t n_nodes;
+    const double* boxes;     // 6 per BVH entry
+    const double* spheres;   // 4 per sphere: cx cy cz r
+    const double* quads;     // 16 per quad: n(3) d q(3) u(3) v(3) w(3)
+    const double* tris;      // 16 per triangle, same layout
+    const double* quadrics;  // 10 per quadric: p1(3) p2(3) p3(3) j
+    const uint32_t* sphere_mat; const uint32_t* sphere_id;
+    const uint32_t* quad_mat;   const uint32_t* quad_id;
+    const uint32_t* tri_mat;    const uint32_t* tri_id;
+    const uint32_t* quadric_mat; const uint32_t* quadric_id;
+    const rt_medium* media;
+    const rt_xform_op* ops;
+    const rt_chain* chains;
+    const rt_material* mats;
+    const rt_texture* texs;
+    const uint8_t* texels;        // all images back to back
+    const uint32_t* image_desc;   // per slot: byte offset/3 (pixel offset), width, height
+    const double* perlin_vec;     // per slot 256*3
+    const uint32_t* perlin_perm;  // per slot 3*256
+};
+
+struct Ray {  // src/ray.rs:4-8; `a` caches direction.length_squared()
+    V3 o, d, inv;
+    double a;
+    bool inv_ok;
+};
+RT_HD V3 ray_at(const Ray& r, double t) { return r.o + r.d * t; }  // ray.rs:11-13
+RT_HD void ray_need_inv(Ray& r) {  // ray.rs:14-19; only AABB::hit reads it
+    if (!r.inv_ok) {
+        r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+        r.inv_ok = true;
+    }
+}
+RT_HD Ray ray_world(V3 o, V3 d) {
+    Ray r;
+    r.o = o; r.d = d; r.a = len2(d); r.inv_ok = false; r.inv = mk(0, 0, 0);
+    return r;
+}
+// The ray an object under `chain` sees: Translate::hit (hittable/mod.rs:80) and RotateY::hit (:121-124) applied
+// outermost first.
+RT_HD Ray ray_in_chain(const DScene& S, const Ray& w, uint32_t chain) {
+    Ray r = w;
+    if (chain == 0) return r;
+    rt_chain c = S.chains[chain];
+    bool rotated = false;
+    for (uint32_t k = 0; k < c.n_ops; ++k) {
+        const rt_xform_op& op = S.ops[c.first_op + k];
+        if (op.kind == RT_XF_TRANSLATE) {
+            r.o = r.o - mk(op.v[0], op.v[1], op.v[2]);
+        } else {
+            r.o = rotate_y(r.o, op.v[1], op.v[0]);
+            r.d = rotate_y(r.d, op.v[1], op.v[0]);
+            rotated = true;
+        }
+    }
+    if (rotated) {
+        r.a = len2(r.d);
+        r.inv_ok = false;
+    }
+    return r;
+}
+
+// Per-lane array of ray intervals, one slot per nesting level of BVH / medium entries.  `stride` is the number
+// of lanes sharing the backing store (LDS on the device: slot l of lane i lives at base[l * stride + i]).
+struct Levels {
+    double2* base;
+    uint32_t stride;
+};
+RT_HD void lv_set(const Levels& L, uint32_t l, double s, double e) {
+    double2 v; v.x = s; v.y = e;
+    L.base[l * L.stride] = v;
+}
+RT_HD double2 lv_get(const Levels& L, uint32_t l) { return L.base[l * L.stride]; }
+
+struct Best {
+    double t;        // closest accepted t so far (inf when none)
+    uint32_t ref;    // RT_NO_HIT when none
+    uint32_t chain;
+};
+struct Tally {
+    uint32_t node_tests, prim_tests;
+};
+
+// AABB::hit, aabb.rs:164-200: narrows (s, e) axis by axis, miss as soon as e <= s.
+RT_HD bool slab(const double* b, const Ray& r, double& s, double& e) {
+    {
+        double t0 = (b[0] - r.o.x) * r.inv.x, t1 = (b[1] - r.o.x) * r.inv.x;
+        if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
+        if (e <= s) return false;
+    }
+    {
+        double t0 = (b[2] - r.o.y) * r.inv.y, t1 = (b[3] - r.o.y) * r.inv.y;
+        if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
+        if (e <= s) return false;
+    }
+    {
+        double t0 = (b[4] - r.o.z) * r.inv.z, t1 = (b[5] - r.o.z) * r.inv.z;
+        if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
+        if (e <= s) return false;
+    }
+    return true;
+}
+
+// Sphere::hit, sphere.rs:40-63 (the part that decides t; the record is rebuilt in finalize()).
+RT_HD bool sphere_t(const double* sp, const Ray& r, double s, double e, double& t) {
+    V3 oc = mk(sp[0], sp[1], sp[2]) - r.o;
+    double h = dot(oc, r.d);
+    double c = len2(oc) - sp[3] * sp[3];
+    double disc = h * h - r.a * c;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double root = (h - sq) / r.a;
+    if (!(s <= root && root < e)) {
+        root = (h + sq) / r.a;
+        if (!(s <= root && root < e)) return false;
+    }
+    t = root;
+    return true;
+}
+// Parallelogram::hit, parallelogram.rs:96-120: closed interval, tested before the parallel check.
+RT_HD bool quad_t(const double* q, const Ray& r, double s, double e, double& t_out) {
+    V3 n = ld3(q);
+    double den = dot(n, r.d);
+    double t = (q[3] - dot(n, r.o)) / den;
+    if (e < t || t < s) return false;
+    if (fabs(den) < 1e-8) return false;
+    V3 ph = ray_at(r, t) - ld3(q + 4);
+    double alpha = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
+    double beta = dot(ld3(q + 13), cross(ld3(q + 7), ph));
+    if (!(0.0 <= alpha && alpha < 1.0 && 0.0 <= beta && beta < 1.0)) return false;  // :139-143
+    t_out = t;
+    return true;
+}
+// Triangle::hit, triangle.rs:123-144: parallel check first, half-open interval, strict barycentric test.
+RT_HD bool tri_t(const double* q, const Ray& r, double s, double e, double& t_out) {
+    V3 n = ld3(q);
+    double den = dot(n, r.d);
+    if (fabs(den) < 1e-8) return false;
+    double t = (q[3] - dot(n, r.o)) / den;
+    if (!(s <= t && t < e)) return false;
+    V3 ph = ray_at(r, t) - ld3(q + 4);
+    double alpha = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
+    double beta = dot(ld3(q + 13), cross(ld3(q + 7), ph));
+    if (!(alpha > 0.0 && beta > 0.0 && alpha + beta < 1.0)) return false;  // :163-165
+    t_out = t;
+    return true;
+}
+// Quadric::hit, quadric.rs:26-54.
+RT_HD V3 prod1(V3 u, V3 v) { return mk(u.x * v.y, u.x * v.z, u.y * v.z); }  // :91-97
+RT_HD V3 anticross(V3 u, V3 v) {                                            // :99-105
+    return mk(u.x * v.y + u.y * v.x, u.x * v.z + u.z * v.x, u.y * v.z + u.z * v.y);
+}
+RT_HD bool quadric_t(const double* q, const Ray& r, double s, double e, double& t) {
+    V3 p1 = ld3(q), p2 = ld3(q + 3), p3 = ld3(q + 6);
+    V3 o = r.o, d = r.d;
+    double a = dot(p1, d * d) + dot(p2, prod1(d, d));
+    double h = -dot(p1, d * o) - 0.5 * dot(p2, anticross(d, o)) - 0.5 * dot(p3, d);
+    double c = dot(p1, o * o) + dot(p2, anticross(o, o)) + dot(p3, o) + q[9];
+    double disc = h * h - a * c;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double root = (h - sq) / a;
+    if (!(s <= root && root < e)) {
+        root = (h + sq) / a;
+        if (!(s <= root && root < e)) return false;
+    }
+    t = root;
+    return true;
+}
+
+// Walks entries [i, iend) of the flattened tree in order, which is the order of the reference's recursion:
+// HittableSlice::hit in list order with the interval end shrunk to the closest hit so far
+// (hittable_list.rs:88-102), BVHNode::hit narrowing the interval by its box and handing it to left, then right
+// with end = left's t (bvh.rs:29-60).  The interval an entry sees is (start, min(end, best.t)) of its level: a
+// minimum over nested narrowings does not depend on when each was taken, so this equals the value the recursion
+// passes down.  MEDIA selects whether ConstantMedium entries may occur (not inside a medium's own boundary).
+template <bool MEDIA, bool COUNT>
+RT_HD void walk(const DScene& S, const Ray& wray, uint32_t i, uint32_t iend, const Levels& L, Rng& rng, Best& best,
+                Ray& cur, uint32_t& cur_chain, Tally& tally) {
+    while (i < iend) {
+        const rt_node n = S.nodes[i];
+        if (n.chain != cur_chain) {
+            cur = ray_in_chain(S, wray, n.chain);
+            cur_chain = n.chain;
+        }
+        double2 iv = lv_get(L, n.level);
+        double s = iv.x;
+        double e = fmin(iv.y, best.t);
+        switch (n.kind) {
+            case RT_NODE_BVH: {
+                if (COUNT) tally.node_tests++;
+                ray_need_inv(cur);
+                if (slab(S.boxes + 6u * n.first, cur, s, e)) {
+                    lv_set(L, n.level + 1u, s, e);
+                    i = i + 1u;
+                } else {
+                    i = n.skip;
+                }
+                break;
+            }
+            case RT_NODE_SPHERES: {
+                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
+                    if (COUNT) tally.prim_tests++;
+                    double t;
+                    if (sphere_t(S.spheres + 4u * k, cur, s, e, t)) {
+                        best.t = t; best.ref = make_ref(RT_NODE_SPHERES, k); best.chain = n.chain;
+                        e = t;  // t < e already
+                    }
+                }
+                i = i + 1u;
+                break;
+            }
+            case RT_NODE_QUADS: {
+                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
+                    if (COUNT) tally.prim_tests++;
+                    double t;
+                    if (quad_t(S.quads + 16u * k, cur, s, e, t)) {
+                        best.t = t; best.ref = make_ref(RT_NODE_QUADS, k); best.chain = n.chain;
+                        e = t;  // t <= e already
+                    }
+                }
+                i = i + 1u;
+                break;
+            }
+            case RT_NODE_TRIANGLES: {
+                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
+                    if (COUNT) tally.prim_tests++;
+                    double t;
+                    if (tri_t(S.tris + 16u * k, cur, s, e, t)) {
+                        best.t = t; best.ref = make_ref(RT_NODE_TRIANGLES, k); best.chain = n.chain;
+                        e = t;
+                    }
+                }
+                i = i + 1u;
+                break;
+            }
+            case RT_NODE_QUADRICS: {
+                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
+                    if (COUNT) tally.prim_tests++;
+                    double t;
+                    if (quadric_t(S.quadrics + 10u * k, cur, s, e, t)) {
+                        best.t = t; best.ref = make_ref(RT_NODE_QUADRICS, k); best.chain = n.chain;
+                        e = t;
+                    }
+                }
+                i = i + 1u;
+                break;
+            }
+            case RT_NODE_MEDIUM: {
+                if constexpr (MEDIA) {
+                    // ConstantMedium::hit, constant_medium.rs:46-93
+                    if (COUNT) tally.prim_tests++;
+                    const rt_medium m = S.media[n.first];
+                    double ray_length = sqrt(cur.a);  // of the ray the medium itself receives
+                    Best b1; b1.t = RT_INF; b1.ref = RT_NO_HIT; b1.chain = 0;
+                    lv_set(L, n.level + 1u, -RT_INF, RT_INF);
+                    walk<false, COUNT>(S, wray, i + 1u, n.skip, L, rng, b1, cur, cur_chain, tally);
+                    if (b1.ref != RT_NO_HIT) {
+                        Best b2; b2.t = RT_INF; b2.ref = RT_NO_HIT; b2.chain = 0;
+                        lv_set(L, n.level + 1u, b1.t + 0.0001, RT_INF);
+                        walk<false, COUNT>(S, wray, i + 1u, n.skip, L, rng, b2, cur, cur_chain, tally);
+                        if (b2.ref != RT_NO_HIT) {
+                            double t1 = fmax(b1.t, s);
+                            double t2 = fmin(b2.t, e);
+                            t1 = fmax(t1, 0.0);
+                            double inside = (t2 - t1) * ray_length;
+                            double x = rng_range(rng, 0.0, 1.0);
+                            double hit_distance = m.neg_inv_density * log(x);
+                            if (!(hit_distance > inside)) {
+                                best.t = t1 + hit_distance / ray_length;
+                                best.ref = make_ref(RT_NODE_MEDIUM, n.first);
+                                best.chain = n.chain;
+                            }
+                        }
+                    }
+                }
+                i = n.skip;
+                break;
+            }
+            default:
+                i = iend;  // unreachable for a validated scene
+                break;
+        }
+    }
+}
+
+// world.hit(ray, tmin..tmax) (camera.rs:363): returns the closest hit as (t, ref, chain).
+template <bool COUNT>
+RT_HD Best closest_hit(const DScene& S, const Ray& wray, double tmin, double tmax, const Levels& L, Rng& rng,
+                       Tally& tally) {
+    Best best; best.t = RT_INF; best.ref = RT_NO_HIT; best.chain = 0;
+    lv_set(L, 0u, tmin, tmax);
+    Ray cur = wray;
+    uint32_t cur_chain = 0;
+    walk<true, COUNT>(S, wray, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct Rec {  // hittable/mod.rs:18-31
+    V3 p, n;
+    double u, v;
+    uint32_t mat, prim_id;
+    bool front;
+};
+RT_HD void face_normal(Rec& r, V3 dir, V3 outward) {  // hittable/mod.rs:51-58
+    r.front = dot(outward, dir) < 0.0;
+    r.n = r.front ? outward : -outward;
+}
+RT_HD void sphere_uv(V3 p, double& u, double& v) {  // sphere.rs:90-98
+    double theta = acos(-p.y);
+    double phi = atan2(-p.z, p.x) + RT_PI;
+    u = phi / (2.0 * RT_PI);
+    v = theta / RT_PI;
+}
+// Rebuilds the HitRecord of the closest hit exactly as the primitive's hit() fills it (sphere.rs:65-73,
+// parallelogram.rs:113-128, triangle.rs:137-152, quadric.rs:56-82, constant_medium.rs:79-90) in the ray space of
+// its chain, then maps p and normal back out through the instances (hittable/mod.rs:88,131-132).
+// WANT_UV = false skips the sphere's acos/atan2 when the caller knows the material ignores (u, v).
+template <bool WANT_UV>
+RT_HD Rec finalize(const DScene& S, const Ray& wray, const Best& b) {
+    Rec r;
+    Ray ray = ray_in_chain(S, wray, b.chain);
+    uint32_t kind = b.ref >> RT_REF_KIND_SHIFT, k = b.ref & RT_REF_INDEX_MASK;
+    r.u = 0.0; r.v = 0.0;
+    r.p = ray_at(ray, b.t);
+    switch (kind) {
+        case RT_NODE_SPHERES: {
+            const double* sp = S.spheres + 4u * k;
+            V3 outward = (r.p - mk(sp[0], sp[1], sp[2])) / sp[3];
+            face_normal(r, ray.d, outward);
+            if (WANT_UV) sphere_uv(outward, r.u, r.v);
+            r.mat = S.sphere_mat[k]; r.prim_id = S.sphere_id[k];
+            break;
+        }
+        case RT_NODE_QUADS:
+        case RT_NODE_TRIANGLES: {
+            const double* q = (kind == RT_NODE_QUADS ? S.quads : S.tris) + 16u * k;
+            V3 ph = r.p - ld3(q + 4);
+            r.u = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
+            r.v = dot(ld3(q + 13), cross(ld3(q + 7), ph));
+            face_normal(r, ray.d, ld3(q));
+            if (kind == RT_NODE_QUADS) { r.mat = S.quad_mat[k]; r.prim_id = S.quad_id[k]; }
+            else { r.mat = S.tri_mat[k]; r.prim_id = S.tri_id[k]; }
+            break;
+        }
+        case RT_NODE_QUADRICS: {
+            const double* q = S.quadrics + 10u * k;
+            V3 p1 = ld3(q), p2 = ld3(q + 3), p3 = ld3(q + 6), p = r.p;
+            V3 g = mk(2.0 * p1.x * p.x + p2.x * p.y + p2.y * p.z, 2.0 * p1.y * p.y + p2.x * p.x + p2.z * p.z,
+                      2.0 * p1.z * p.z + p2.y * p.x + p2.z * p.y) + p3;
+            face_normal(r, ray.d, unit(g));
+            r.mat = S.quadric_mat[k]; r.prim_id = S.quadric_id[k];
+            break;
+        }
+        default: {  // RT_NODE_MEDIUM
+            r.n = mk(1.0, 0.0, 0.0);
+            r.front = true;
+            r.mat = S.media[k].material; r.prim_id = S.media[k].prim_id;
+            break;
+        }
+    }
+    if (b.chain != 0) {
+        rt_chain c = S.chains[b.chain];
+        for (uint32_t j = c.n_ops; j > 0; --j) {
+            const rt_xform_op& op = S.ops[c.first_op + j - 1u];
+            if (op.kind == RT_XF_TRANSLATE) {
+                r.p = r.p + mk(op.v[0], op.v[1], op.v[2]);
+            } else {
+                r.p = rotate_y(r.p, op.v[1], -op.v[0]);
+                r.n = rotate_y(r.n, op.v[1], -op.v[0]);
+            }
+        }
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// perlin.rs:46-143
+RT_HD double perlin_noise(const double* vec, const uint32_t* perm, V3 p) {
+    double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    long long i = (long long)fx, j = (long long)fy, k = (long long)fz;
+    double uu = u * u * (3.0 - 2.0 * u);
+    double vv = v * v * (3.0 - 2.0 * v);
+    double ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                uint32_t fi = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+                V3 c = ld3(vec + 3u * fi);
+                double a = (double)di, b = (double)dj, cc = (double)dk;
+                V3 wv = mk(u - a, v - b, w - cc);
+                accum += (a * uu + (1.0 - a) * (1.0 - uu)) * (b * vv + (1.0 - b) * (1.0 - vv)) *
+                         (cc * ww + (1.0 - cc) * (1.0 - ww)) * dot(c, wv);
+            }
+    return accum;
+}
+RT_HD double perlin_turbulence(const double* vec, const uint32_t* perm, V3 p, int depth) {  // :79-92
+    double accum = 0.0, weight = 1.0;
+    V3 tp = p;
+    for (int i = 0; i < depth; ++i) {
+        accum += weight * perlin_noise(vec, perm, tp);
+        weight *= 0.5;
+        tp = 2.0 * tp;
+    }
+    return fabs(accum);
+}
+RT_HD bool tex_needs_uv(const DScene& S, uint32_t tid) {
+    // conservative: only image textures read (u, v); a checker may lead to one
+    return S.texs[tid].kind == RT_TEX_IMAGE || S.texs[tid].kind == RT_TEX_CHECKER;
+}
+// Texture::value, texture.rs:25-29 (solid), :59-80 (checker), :116-136 (image), :143-157 (perlin).
+RT_HD V3 tex_value(const DScene& S, uint32_t tid, double u, double v, V3 p) {
+    for (int guard = 0; guard < 64; ++guard) {
+        const rt_texture t = S.texs[tid];
+        if (t.kind == RT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);
+        if (t.kind == RT_TEX_CHECKER) {
+            long long xi = (long long)floor(t.scale * p.x);
+            long long yi = (long long)floor(t.scale * p.y);
+            long long zi = (long long)floor(t.scale * p.z);
+            tid = ((xi + yi + zi) % 2 == 0) ? t.a : t.b;
+            continue;
+        }
+        if (t.kind == RT_TEX_IMAGE) {
+            uint32_t off = S.image_desc[3u * t.a], w = S.image_desc[3u * t.a + 1u], h = S.image_desc[3u * t.a + 2u];
+            double cu = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+            double cv0 = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            double cv = 1.0 - cv0;
+            uint32_t ui = (uint32_t)((double)w * cu), vi = (uint32_t)((double)h * cv);
+            if (ui >= w) ui = w - 1u;  // texture.rs:124-127 would index one past the edge at u == 1 / v == 0
+            if (vi >= h) vi = h - 1u;
+            const uint8_t* px = S.texels + 3u * ((size_t)off + (size_t)vi * w + ui);
+            double sc = 1.0 / 255.0;
+            return mk((double)px[0] * sc, (double)px[1] * sc, (double)px[2] * sc);
+        }
+        // RT_TEX_PERLIN
+        const double* vec = S.perlin_vec + 768u * t.a;
+        const uint32_t* perm = S.perlin_perm + 768u * t.a;
+        return mk(0.5, 0.5, 0.5) * (1.0 + sin(t.scale * p.z + 10.0 * perlin_turbulence(vec, perm, p, 7)));
+    }
+    return mk(0, 0, 0);
+}
+
+// Material::emitted + Material::scatter (material.rs).  Returns false when the path ends here; `emit` is the
+// emitted colour (zero for everything but DiffuseLight).
+RT_HD double reflectance(double cosine, double ri) {  // material.rs:161-166
+    double r0 = (1.0 - ri) / (1.0 + ri);
+    double r0s = r0 * r0;
+    return r0s + (1.0 - r0s) * pow(1.0 - cosine, 5.0);
+}
+RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& rec, Rng& rng, V3& out_d, V3& att,
+                   V3& emit) {
+    emit = mk(0, 0, 0);
+    switch (m.kind) {
+        case RT_MAT_LAMBERTIAN: {  // :45-68
+            V3 temp = rec.n + random_unit_vector(rng);
+            out_d = near_zero(temp) ? rec.n : temp;
+            att = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+            return true;
+        }
+        case RT_MAT_METAL: {  // :88-104
+            V3 reflected = reflect(ray_d, rec.n);
+            out_d = unit(reflected) + (m.param * random_unit_vector(rng));
+            att = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+            return true;
+        }
+        case RT_MAT_DIELECTRIC: {  // :120-159
+            double ratio = rec.front ? 1.0 / m.param : m.param;
+            V3 ud = unit(ray_d);
+            double cos_theta = fmin(dot(rec.n, -ud), 1.0);
+            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+            bool cannot_refract = ratio * sin_theta > 1.0;
+            bool refl = reflectance(cos_theta, ratio) > rng_range(rng, 0.0, 1.0);
+            out_d = (cannot_refract | refl) ? reflect(ud, rec.n) : refract(ud, rec.n, ratio);
+            att = mk(1.0, 1.0, 1.0);
+            return true;
+        }
+        case RT_MAT_DIFFUSE_LIGHT: {  // :185-189
+            emit = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+            return false;
+        }
+        default: {  // RT_MAT_ISOTROPIC :196-208
+            out_d = random_unit_vector(rng);
+            att = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+            return true;
+        }
+    }
+}
+
+// Camera::get_ray, camera.rs:479-507.
+RT_HD void camera_ray(const rt_camera& c, uint32_t i, uint32_t j, Rng& rng, V3& o, V3& d) {
+    double ox = rng_range(rng, -0.5, 0.5);
+    double oy = rng_range(rng, -0.5, 0.5);
+    V3 ps = ld3(c.pixel00) + (ld3(c.delta_u) * ((double)i + ox)) + (ld3(c.delta_v) * ((double)j + oy));
+    if (c.defocus_angle <= 0.0) {
+        o = ld3(c.center);
+    } else {
+        double px, py;
+        for (;;) {  // random_in_unit_disk, point3/mod.rs:263-274
+            px = rng_range(rng, -1.0, 1.0);
+            py = rng_range(rng, -1.0, 1.0);
+            if (px * px + py * py + 0.0 * 0.0 < 1.0) break;
+        }
+        o = ld3(c.center) + px * ld3(c.disk_u) + py * ld3(c.disk_v);
+    }
+    d = ps - o;
+}
+
+// point3/color.rs:17-22,49-68
+RT_HD uint8_t to_byte(double lin) {
+    double g = lin > 0.0 ? sqrt(lin) : 0.0;
+    double c = g < 0.0 ? 0.0 : (g > 0.999 ? 0.999 : g);
+    double s = 256.0 * c;
+    if (!(s == s)) return 0;
+    if (s >= 255.0) return 255;
+    if (s <= 0.0) return 0;
+    return (uint8_t)s;
+}
+
+}  // namespace rt

@@ -1,0 +1,107 @@
+"""A scene committed to one GPU, and the calls of the C ABI (include/rt_amd.h) that run on it."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RtError, rt_render_opts, rt_stats
+
+
+def _opts(spp_begin, spp_count, max_depth, seed, background, batch_paths=0, flags=0):
+    o = rt_render_opts()
+    o.spp_begin, o.spp_count, o.max_depth, o.flags = spp_begin, spp_count, max_depth, flags
+    o.seed = seed
+    o.background[0], o.background[1], o.background[2] = [float(x) for x in background]
+    o.batch_paths = batch_paths
+    return o
+
+
+def _stats_dict(st):
+    return {k: getattr(st, k) for k, _ in rt_stats._fields_}
+
+
+class Scene:
+    def __init__(self, handle, device):
+        self.L = _lib.amd()
+        self.h = handle
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.rt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RtError(f"rt_amd error {rc}: {_lib.last_error()}")
+
+    def intersect(self, o, d, tmin, tmax, rng3=None, seed=42):
+        """Hittable::hit on a batch of rays -> dict(hit, prim, t, p, n, uv, front, ctr)."""
+        o = np.ascontiguousarray(o, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, dtype=np.float64), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, dtype=np.float64), (n,)))
+        if rng3 is not None:
+            rng3 = np.ascontiguousarray(rng3, dtype=np.uint32).reshape(n, 3)
+        out = {"hit": np.zeros(n, np.uint8), "prim": np.zeros(n, np.uint32), "t": np.zeros(n), "p": np.zeros((n, 3)),
+               "n": np.zeros((n, 3)), "uv": np.zeros((n, 2)), "front": np.zeros(n, np.uint8),
+               "ctr": np.zeros(n, np.uint32)}
+        self._ck(self.L.rt_intersect_batch(self.h, seed, o.ctypes.data, d.ctypes.data, tmin.ctypes.data,
+                                           tmax.ctypes.data, rng3.ctypes.data if rng3 is not None else None, n,
+                                           out["hit"].ctypes.data, out["prim"].ctypes.data, out["t"].ctypes.data,
+                                           out["p"].ctypes.data, out["n"].ctypes.data, out["uv"].ctypes.data,
+                                           out["front"].ctypes.data, out["ctr"].ctypes.data))
+        return out
+
+    def render(self, cam, spp, max_depth, background, seed=42, spp_begin=0, batch_paths=0, counters=False):
+        """Camera::render: returns (film of radiance SUMS, shape (H, W, 3), stats dict)."""
+        film = np.zeros((cam.height, cam.width, 3))
+        st = rt_stats()
+        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _lib.RT_FLAG_COUNTERS if counters else 0)
+        self._ck(self.L.rt_render(self.h, C.byref(cam), C.byref(o), film.ctypes.data, C.byref(st)))
+        return film, _stats_dict(st)
+
+    def render_into(self, cam, spp, max_depth, background, film_device_ptr, seed=42, spp_begin=0, batch_paths=0,
+                    counters=False):
+        """Same, into a caller-owned device buffer of H*W*3 f64 (e.g. a torch tensor's data_ptr())."""
+        st = rt_stats()
+        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _lib.RT_FLAG_COUNTERS if counters else 0)
+        self._ck(self.L.rt_render_device(self.h, C.byref(cam), C.byref(o), film_device_ptr, C.byref(st)))
+        return _stats_dict(st)
+
+    def trace_samples(self, cam, pixel, sample, max_depth, background, seed=42):
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        n = pixel.size
+        rad = np.zeros((n, 3))
+        nr = np.zeros(n, np.uint32)
+        o = _opts(0, 1, max_depth, seed, background)
+        self._ck(self.L.rt_trace_samples(self.h, C.byref(cam), C.byref(o), n, pixel.ctypes.data, sample.ctypes.data,
+                                         rad.ctypes.data, nr.ctypes.data))
+        return rad, nr
+
+    def tonemap(self, film, spp):
+        film = np.ascontiguousarray(film, dtype=np.float64)
+        h, w, _ = film.shape
+        rgb = np.zeros((h, w, 3), np.uint8)
+        self._ck(self.L.rt_tonemap_rgb8(self.h, film.ctypes.data, w, h, spp, rgb.ctypes.data))
+        return rgb
+
+
+def debug_arith(a, b, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = a.size
+    q, r, c, l = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    rc = _lib.amd().rt_debug_arith(device, a.ctypes.data, b.ctypes.data, n, q.ctypes.data, r.ctypes.data,
+                                   c.ctypes.data, l.ctypes.data)
+    if rc != 0:
+        raise RtError(_lib.last_error())
+    return q, r, c, l

@@ -1,0 +1,142 @@
+"""Shared test plumbing: paired scene construction (product host layer + oracle), the CPU simulator of the device
+functions (tests/hostsim), ray-batch generation and comparison helpers."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from raytracer_amd import HostBuilder, scenes  # noqa: E402
+from raytracer_amd import _lib  # noqa: E402
+from raytracer_amd.builder import camera_new as host_camera_new  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+SMALL = {  # config -> keyword overrides that keep CPU tests quick
+    "C1": dict(width=64, spp=2),
+    "C2": dict(width=48, spp=2),
+    "C3": dict(width=48, spp=2),
+    "C4": dict(width=48, spp=2),
+    "C5": dict(width=48, spp=2),
+}
+
+
+def build_pair(config, **kw):
+    """The same scene described to the product's host layer and to the oracle."""
+    hs = scenes.build(config, HostBuilder(), **kw)
+    os_ = scenes.build(config, orc.OracleBuilder(), **kw)
+    return hs, os_
+
+
+def cameras(spec):
+    """(rt_camera from the product host layer, orc_camera from the oracle) for a SceneSpec."""
+    hc = host_camera_new(image_width=spec.width, **spec.camera)
+    oc = orc.camera_new(image_width=spec.width, **spec.camera)
+    return hc, oc
+
+
+class sim_scene(C.Structure):
+    _fields_ = [(n, C.c_void_p) if n != "n_nodes" else (n, C.c_uint64) for n in
+                ["nodes", "n_nodes", "boxes", "spheres", "quads", "tris", "quadrics", "sphere_mat", "sphere_id",
+                 "quad_mat", "quad_id", "tri_mat", "tri_id", "quadric_mat", "quadric_id", "media", "ops", "chains",
+                 "mats", "texs", "texels", "image_desc", "perlin_vec", "perlin_perm"]]
+
+
+_SIM = None
+
+
+def _sim_lib():
+    global _SIM
+    if _SIM is None:
+        so = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
+        src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
+        core = os.path.join(ROOT, "raytracer_amd", "csrc", "rt_core.h")
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-host-only", "-x", "hip", "-O2", "-std=c++17", "-fPIC",
+                                   "-shared", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", so, src])
+        _SIM = C.CDLL(so)
+    return _SIM
+
+
+class HostSim:
+    """Runs rt_core.h's walk / finalize / scatter on the CPU over a HostBuilder's flattened arrays."""
+
+    ORDER = {"nodes": 0, "boxes": 1, "spheres": 2, "quads": 3, "tris": 4, "quadrics": 5, "media": 6, "ops": 7,
+             "chains": 8, "mats": 9, "texs": 10, "sphere_id": 11, "quad_id": 12, "tri_id": 13, "quadric_id": 14,
+             "sphere_mat": 15, "quad_mat": 16, "tri_mat": 17, "quadric_mat": 18, "texels": 19, "image_desc": 20,
+             "perlin_vec": 21, "perlin_perm": 22}
+
+    def __init__(self, builder):
+        self.builder = builder  # keeps the arrays alive
+        self.sc = sim_scene()
+        for name, what in self.ORDER.items():
+            p, n = builder.flat_ptr(what)
+            setattr(self.sc, name, p)
+            if name == "nodes":
+                self.sc.n_nodes = n
+        self.L = _sim_lib()
+
+    def intersect(self, o, d, tmin, tmax, rng3=None, seed=42):
+        o = np.ascontiguousarray(o, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, dtype=np.float64), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, dtype=np.float64), (n,)))
+        if rng3 is not None:
+            rng3 = np.ascontiguousarray(rng3, dtype=np.uint32).reshape(n, 3)
+        out = {"hit": np.zeros(n, np.uint8), "prim": np.zeros(n, np.uint32), "t": np.zeros(n), "p": np.zeros((n, 3)),
+               "n": np.zeros((n, 3)), "uv": np.zeros((n, 2)), "front": np.zeros(n, np.uint8),
+               "ctr": np.zeros(n, np.uint32)}
+        tl = (C.c_uint64 * 2)()
+        vp = C.c_void_p
+        self.L.sim_intersect(C.byref(self.sc), C.c_uint64(seed), vp(o.ctypes.data), vp(d.ctypes.data),
+                             vp(tmin.ctypes.data), vp(tmax.ctypes.data),
+                             vp(rng3.ctypes.data) if rng3 is not None else None, C.c_uint64(n),
+                             vp(out["hit"].ctypes.data), vp(out["prim"].ctypes.data), vp(out["t"].ctypes.data),
+                             vp(out["p"].ctypes.data), vp(out["n"].ctypes.data), vp(out["uv"].ctypes.data),
+                             vp(out["front"].ctypes.data), vp(out["ctr"].ctypes.data), tl)
+        out["counters"] = {"node_tests": tl[0], "prim_tests": tl[1]}
+        return out
+
+    def trace_samples(self, cam, pixel, sample, max_depth, background, seed=42):
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        n = pixel.size
+        rad, nr = np.zeros((n, 3)), np.zeros(n, np.uint32)
+        bg = (C.c_double * 3)(*[float(x) for x in background])
+        vp = C.c_void_p
+        self.L.sim_trace_samples(C.byref(self.sc), C.byref(cam), C.c_uint64(seed), C.c_uint32(max_depth), bg,
+                                 C.c_uint64(n), vp(pixel.ctypes.data), vp(sample.ctypes.data), vp(rad.ctypes.data),
+                                 vp(nr.ctypes.data))
+        return rad, nr
+
+
+def path_rays(ospec, ocam, n, bounce, seed=42, rng=None):
+    """Rays entering bounce `bounce` (0 = camera rays) of n random (pixel, sample) pairs, captured from the oracle,
+    with the random-stream position (pixel, sample, draw index) each ray's traversal starts from."""
+    rs = np.random.RandomState(1234 + bounce if rng is None else rng)
+    npix = ocam.width * ocam.height
+    pixel = rs.randint(0, npix, size=n).astype(np.uint32)
+    sample = rs.randint(0, max(ospec.spp, 1), size=n).astype(np.uint32)
+    _, _, cap = ospec.builder.trace_samples(ocam, pixel, sample, ospec.max_depth, ospec.background, seed=seed,
+                                            capture_bounce=bounce)
+    ok = cap["valid"].astype(bool)
+    rng3 = np.stack([pixel, sample, cap["ctr"]], axis=1).astype(np.uint32)
+    return cap["o"][ok], cap["d"][ok], rng3[ok]
+
+
+def assert_hits_equal(got, want, exact=True, what=""):
+    """Bit-exact (or <= 1e-12 relative when exact=False) comparison of two intersect() results."""
+    assert np.array_equal(got["hit"], want["hit"]), f"{what}: hit flags differ at {np.flatnonzero(got['hit'] != want['hit'])[:8]}"
+    assert np.array_equal(got["prim"], want["prim"]), f"{what}: primitive ids differ at {np.flatnonzero(got['prim'] != want['prim'])[:8]}"
+    assert np.array_equal(got["front"], want["front"]), f"{what}: front_face differs"
+    assert np.array_equal(got["ctr"], want["ctr"]), f"{what}: random draw counts differ"
+    for k in ("t", "p", "n", "uv"):
+        if exact:
+            assert np.array_equal(got[k], want[k]), f"{what}: {k} not bit-identical (max abs diff {np.abs(got[k] - want[k]).max()})"
+        else:
+            np.testing.assert_allclose(got[k], want[k], rtol=1e-12, atol=1e-300, err_msg=f"{what}: {k}")

@@ -1,0 +1,88 @@
+// hostsim.cpp -- TEST-ONLY: runs the per-lane device functions of raytracer_amd/csrc/rt_core.h on the CPU, one ray
+// or path at a time, so that the flattened-tree walk can be compared with the oracle in a container without a GPU.
+// It is never linked into librt_amd.so or loaded by the raytracer_amd package.
+#include <cstdint>
+#include <vector>
+
+#include "../../raytracer_amd/csrc/rt_core.h"
+
+using namespace rt;
+
+struct sim_scene {  // host pointers to the arrays of a flattened scene
+    const rt_node* nodes; uint64_t n_nodes;
+    const double* boxes; const double* spheres; const double* quads; const double* tris; const double* quadrics;
+    const uint32_t* sphere_mat; const uint32_t* sphere_id; const uint32_t* quad_mat; const uint32_t* quad_id;
+    const uint32_t* tri_mat; const uint32_t* tri_id; const uint32_t* quadric_mat; const uint32_t* quadric_id;
+    const rt_medium* media; const rt_xform_op* ops; const rt_chain* chains; const rt_material* mats;
+    const rt_texture* texs; const uint8_t* texels; const uint32_t* image_desc; const double* perlin_vec;
+    const uint32_t* perlin_perm;
+};
+
+static DScene to_dscene(const sim_scene* s) {
+    DScene d;
+    d.nodes = s->nodes; d.n_nodes = (uint32_t)s->n_nodes; d.boxes = s->boxes; d.spheres = s->spheres; d.quads = s->quads;
+    d.tris = s->tris; d.quadrics = s->quadrics; d.sphere_mat = s->sphere_mat; d.sphere_id = s->sphere_id;
+    d.quad_mat = s->quad_mat; d.quad_id = s->quad_id; d.tri_mat = s->tri_mat; d.tri_id = s->tri_id;
+    d.quadric_mat = s->quadric_mat; d.quadric_id = s->quadric_id; d.media = s->media; d.ops = s->ops; d.chains = s->chains;
+    d.mats = s->mats; d.texs = s->texs; d.texels = s->texels; d.image_desc = s->image_desc; d.perlin_vec = s->perlin_vec;
+    d.perlin_perm = s->perlin_perm;
+    return d;
+}
+
+extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o3, const double* d3, const double* tmin,
+                             const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim, double* t,
+                             double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out, uint64_t* tallies2) {
+    DScene S = to_dscene(sc);
+    double2 slots[RT_MAX_LEVELS];
+    Levels L; L.base = slots; L.stride = 1;
+    uint64_t nt = 0, pt = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        Tally tally; tally.node_tests = 0; tally.prim_tests = 0;
+        Rng rng = rng_make(seed, rng3 ? rng3[3 * i] : (uint32_t)i, rng3 ? rng3[3 * i + 1] : 0u, rng3 ? rng3[3 * i + 2] : 0u);
+        Ray w = ray_world(ld3(o3 + 3 * i), ld3(d3 + 3 * i));
+        Best b = closest_hit<true>(S, w, tmin[i], tmax[i], L, rng, tally);
+        nt += tally.node_tests; pt += tally.prim_tests;
+        bool h = b.ref != RT_NO_HIT;
+        Rec rec;
+        rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
+        if (h) rec = finalize<true>(S, w, b);
+        hit[i] = h; prim[i] = rec.prim_id; t[i] = h ? b.t : 0.0;
+        p3[3 * i] = rec.p.x; p3[3 * i + 1] = rec.p.y; p3[3 * i + 2] = rec.p.z;
+        n3[3 * i] = rec.n.x; n3[3 * i + 1] = rec.n.y; n3[3 * i + 2] = rec.n.z;
+        uv2[2 * i] = rec.u; uv2[2 * i + 1] = rec.v; front[i] = rec.front; ctr_out[i] = rng.ctr;
+    }
+    tallies2[0] = nt; tallies2[1] = pt;
+    return 0;
+}
+
+extern "C" int sim_trace_samples(const sim_scene* sc, const rt_camera* cam, uint64_t seed, uint32_t max_depth,
+                                 const double* bg, uint64_t n, const uint32_t* pixel, const uint32_t* sample,
+                                 double* radiance3, uint32_t* nrays) {
+    DScene S = to_dscene(sc);
+    double2 slots[RT_MAX_LEVELS];
+    Levels L; L.base = slots; L.stride = 1;
+    for (uint64_t i = 0; i < n; ++i) {
+        Tally tally; tally.node_tests = 0; tally.prim_tests = 0;
+        Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
+        V3 o, d;
+        camera_ray(*cam, pixel[i] % cam->width, pixel[i] / cam->width, rng, o, d);
+        V3 beta = mk(1.0, 1.0, 1.0), lum = mk(0, 0, 0);
+        uint32_t rays = 0;
+        for (uint32_t depth = 0; depth < max_depth; ++depth) {
+            Ray w = ray_world(o, d);
+            rays++;
+            Best b = closest_hit<false>(S, w, 0.001, RT_INF, L, rng, tally);
+            if (b.ref == RT_NO_HIT) { lum = beta * mk(bg[0], bg[1], bg[2]); break; }
+            Rec rec = finalize<true>(S, w, b);
+            V3 nd, att, emit;
+            const rt_material m = S.mats[rec.mat];
+            if (!scatter(S, m, w.d, rec, rng, nd, att, emit)) { lum = beta * emit; break; }
+            beta = beta * att;
+            o = rec.p;
+            d = nd;
+        }
+        radiance3[3 * i] = lum.x; radiance3[3 * i + 1] = lum.y; radiance3[3 * i + 2] = lum.z;
+        nrays[i] = rays;
+    }
+    return 0;
+}
