@@ -140,6 +140,8 @@ typedef struct rt_stats {
     uint64_t rays;       /* world.hit calls: one per bounce including the camera ray (camera.rs:363,429) */
     uint64_t node_tests; /* AABB::hit calls, only with RT_FLAG_COUNTERS */
     uint64_t prim_tests; /* primitive / medium hit calls, only with RT_FLAG_COUNTERS */
+    uint64_t prim_bytes; /* bytes of the primitive records those calls read (sphere 40, quad/triangle 136, quadric 88,
+                            medium 16), only with RT_FLAG_COUNTERS */
     double ms_total;     /* device time of the whole call */
     double ms_traverse;  /* summed duration of the traverse+intersect launches (HIP events) */
     double ms_shade;     /* summed duration of the shade+compact launches */

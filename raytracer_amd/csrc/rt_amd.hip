@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_traverse(DScene S, BatchInfo bi,
                                                          unsigned long long* tallies) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
     if (idx < n) {
         uint32_t p = q.path[idx];
         Rng rng = rng_make(bi.seed, p % bi.npix, bi.sample0 + p / bi.npix, q.ctr[idx]);
@@ -88,9 +88,9 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_traverse(DScene S, BatchInfo bi,
         q.ctr[idx] = rng.ctr;
     }
     if (COUNT) {
-        unsigned long long a = tally.node_tests, b = tally.prim_tests;
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&tallies[0], a); atomicAdd(&tallies[1], b); }
+        unsigned long long a = tally.node_tests, b = tally.prim_tests, c = tally.prim_bytes;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&tallies[0], a); atomicAdd(&tallies[1], b); atomicAdd(&tallies[2], c); }
     }
 }
 
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_intersect_batch(DScene S, uint64
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
     Rng rng = rng_make(seed, rng3 ? rng3[3 * i] : (uint32_t)i, rng3 ? rng3[3 * i + 1] : 0u, rng3 ? rng3[3 * i + 2] : 0u);
     Ray w = ray_world(ld3(o3 + 3 * i), ld3(d3 + 3 * i));
     Best b = closest_hit<false>(S, w, tmin[i], tmax[i], L, rng, tally);
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_samples(DScene S, rt_camer
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
     Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
     V3 o, d;
     camera_ray(cam, pixel[i] % cam.width, pixel[i] / cam.width, rng, o, d);
@@ -684,7 +684,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     hipStream_t sm = s->stream;
     HIP_TRY(hipEventRecord(s->ev[0], sm));
     hipLaunchKernelGGL(k_fill, dim3((3u * npix + 255u) / 256u), dim3(256), 0, sm, film, (size_t)3 * npix, -0.0);
-    if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 16, sm));
+    if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 24, sm));
     const size_t lds = levels_lds(s, TRAV_BLOCK);
 
     for (uint32_t s0 = 0; s0 < o->spp_count; s0 += spb) {
@@ -735,10 +735,11 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[3]));
     st.ms_total = ms;
     if (count) {
-        unsigned long long h[2];
-        HIP_TRY(hipMemcpy(h, s->d_tallies, 16, hipMemcpyDeviceToHost));
+        unsigned long long h[3];
+        HIP_TRY(hipMemcpy(h, s->d_tallies, 24, hipMemcpyDeviceToHost));
         st.node_tests = h[0];
         st.prim_tests = h[1];
+        st.prim_bytes = h[2];
     }
     if (stats) *stats = st;
     return RT_OK;

@@ -199,7 +199,7 @@ struct Best {
     uint32_t chain;
 };
 struct Tally {
-    uint32_t node_tests, prim_tests;
+    uint32_t node_tests, prim_tests, prim_bytes;
 };
 
 // AABB::hit, aabb.rs:164-200: narrows (s, e) axis by axis, miss as soon as e <= s.
@@ -321,7 +321,7 @@ RT_HD void walk(const DScene& S, const Ray& wray, uint32_t i, uint32_t iend, con
             }
             case RT_NODE_SPHERES: {
                 for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) tally.prim_tests++;
+                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 40u; }
                     double t;
                     if (sphere_t(S.spheres + 4u * k, cur, s, e, t)) {
                         best.t = t; best.ref = make_ref(RT_NODE_SPHERES, k); best.chain = n.chain;
@@ -333,7 +333,7 @@ RT_HD void walk(const DScene& S, const Ray& wray, uint32_t i, uint32_t iend, con
             }
             case RT_NODE_QUADS: {
                 for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) tally.prim_tests++;
+                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
                     double t;
                     if (quad_t(S.quads + 16u * k, cur, s, e, t)) {
                         best.t = t; best.ref = make_ref(RT_NODE_QUADS, k); best.chain = n.chain;
@@ -345,7 +345,7 @@ RT_HD void walk(const DScene& S, const Ray& wray, uint32_t i, uint32_t iend, con
             }
             case RT_NODE_TRIANGLES: {
                 for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) tally.prim_tests++;
+                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
                     double t;
                     if (tri_t(S.tris + 16u * k, cur, s, e, t)) {
                         best.t = t; best.ref = make_ref(RT_NODE_TRIANGLES, k); best.chain = n.chain;
@@ -357,7 +357,7 @@ RT_HD void walk(const DScene& S, const Ray& wray, uint32_t i, uint32_t iend, con
             }
             case RT_NODE_QUADRICS: {
                 for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) tally.prim_tests++;
+                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
                     double t;
                     if (quadric_t(S.quadrics + 10u * k, cur, s, e, t)) {
                         best.t = t; best.ref = make_ref(RT_NODE_QUADRICS, k); best.chain = n.chain;
@@ -370,7 +370,7 @@ RT_HD void walk(const DScene& S, const Ray& wray, uint32_t i, uint32_t iend, con
             case RT_NODE_MEDIUM: {
                 if constexpr (MEDIA) {
                     // ConstantMedium::hit, constant_medium.rs:46-93
-                    if (COUNT) tally.prim_tests++;
+                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
                     const rt_medium m = S.media[n.first];
                     double ray_length = sqrt(cur.a);  // of the ray the medium itself receives
                     Best b1; b1.t = RT_INF; b1.ref = RT_NO_HIT; b1.chain = 0;

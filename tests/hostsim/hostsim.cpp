@@ -37,7 +37,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
     Levels L; L.base = slots; L.stride = 1;
     uint64_t nt = 0, pt = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        Tally tally; tally.node_tests = 0; tally.prim_tests = 0;
+        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
         Rng rng = rng_make(seed, rng3 ? rng3[3 * i] : (uint32_t)i, rng3 ? rng3[3 * i + 1] : 0u, rng3 ? rng3[3 * i + 2] : 0u);
         Ray w = ray_world(ld3(o3 + 3 * i), ld3(d3 + 3 * i));
         Best b = closest_hit<true>(S, w, tmin[i], tmax[i], L, rng, tally);
@@ -62,7 +62,7 @@ extern "C" int sim_trace_samples(const sim_scene* sc, const rt_camera* cam, uint
     double2 slots[RT_MAX_LEVELS];
     Levels L; L.base = slots; L.stride = 1;
     for (uint64_t i = 0; i < n; ++i) {
-        Tally tally; tally.node_tests = 0; tally.prim_tests = 0;
+        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
         Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
         V3 o, d;
         camera_ray(*cam, pixel[i] % cam->width, pixel[i] / cam->width, rng, o, d);
