@@ -42,7 +42,10 @@ static int fail(int code, const char* fmt, ...) {
 struct Queue {
     double *ox, *oy, *oz, *dx, *dy, *dz;  // ray
     double *br, *bg, *bb;                 // throughput (product of attenuations so far)
-    uint32_t* path;                       // index of the path inside the batch = s_local * npix + pixel
+    uint32_t* pix;                        // pixel index j * width + i
+    uint32_t* smp;                        // global sample index (with pix: the path's random stream)
+    uint32_t* slot;                       // where the path's radiance goes in the luminance buffer
+    uint32_t* born;                       // iteration the path was generated in (depth = iteration - born)
     uint32_t* ctr;                        // next draw index of the path's random stream
 };
 struct HitBuf {
@@ -50,81 +53,211 @@ struct HitBuf {
     uint32_t* ref;
     uint32_t* chain;
 };
-struct BatchInfo {
-    uint32_t npix, width;
-    uint32_t sample0;  // global sample index of s_local = 0
-    uint64_t seed;
-};
 
 extern __shared__ double2 g_levels[];
 
-__global__ void __launch_bounds__(TRAV_BLOCK) k_raygen(rt_camera cam, BatchInfo bi, uint32_t n, Queue q) {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    uint32_t pixel = idx % bi.npix, s_local = idx / bi.npix;
-    Rng rng = rng_make(bi.seed, pixel, bi.sample0 + s_local, 0u);
+// Camera::get_ray (camera.rs:479-492) for one batch of `nsamples` consecutive samples of every pixel, appended to
+// the queue at `base`.  Batch-local path j = s_local * npix + pixel keeps primary rays of neighbouring pixels in
+// neighbouring lanes.
+__global__ void __launch_bounds__(256) k_raygen(rt_camera cam, uint64_t seed, uint32_t npix, uint32_t sample0,
+                                                 uint32_t n, uint32_t base, uint32_t slot0, uint32_t iter, Queue q) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t pixel = j % npix, s_local = j / npix;
+    Rng rng = rng_make(seed, pixel, sample0 + s_local, 0u);
     V3 o, d;
-    camera_ray(cam, pixel % bi.width, pixel / bi.width, rng, o, d);
+    camera_ray(cam, pixel % cam.width, pixel / cam.width, rng, o, d);
+    uint32_t idx = base + j;
     q.ox[idx] = o.x; q.oy[idx] = o.y; q.oz[idx] = o.z;
     q.dx[idx] = d.x; q.dy[idx] = d.y; q.dz[idx] = d.z;
     q.br[idx] = 1.0; q.bg[idx] = 1.0; q.bb[idx] = 1.0;
-    q.path[idx] = idx;
+    q.pix[idx] = pixel;
+    q.smp[idx] = sample0 + s_local;
+    q.slot[idx] = slot0 + j;
+    q.born[idx] = iter;
     q.ctr[idx] = rng.ctr;
 }
 
-// world.hit(ray, 0.001..inf) for every queued path (camera.rs:363).
+// What a traverse launch works on: the queue of rays, where the closest hits go, and -- for caller-supplied batches
+// only -- per-ray intervals (a render uses 0.001..inf, camera.rs:363).
+struct TravArgs {
+    Queue q;
+    HitBuf hb;
+    uint64_t seed;
+    uint32_t n;
+    const double* tmin;     // nullable
+    const double* tmax;     // nullable
+};
+__device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, RngPos& rng, double& tmin, double& tmax) {
+    rng.k0 = (uint32_t)a.seed; rng.k1 = (uint32_t)(a.seed >> 32);
+    rng.pixel = a.q.pix[idx]; rng.sample = a.q.smp[idx];
+    rng.ctr = a.q.ctr[idx];
+    tmin = a.tmin ? a.tmin[idx] : 0.001;
+    tmax = a.tmax ? a.tmax[idx] : RT_INF;
+}
+__device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long long* tallies) {
+    unsigned long long a = tally.node_tests, b = tally.prim_tests, c = tally.prim_bytes;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&tallies[0], a); atomicAdd(&tallies[1], b); atomicAdd(&tallies[2], c); }
+}
+
+// world.hit(ray, 0.001..inf) for every queued path (camera.rs:363), for trees WITHOUT BVH entries: one lane per
+// ray, all lanes visit the same entries in the same order, scene data comes through scalar loads.
 template <bool COUNT>
-__global__ void __launch_bounds__(TRAV_BLOCK) k_traverse(DScene S, BatchInfo bi, uint32_t n, Queue q, HitBuf hb,
-                                                         unsigned long long* tallies) {
+__global__ void __launch_bounds__(TRAV_BLOCK) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
-    if (idx < n) {
-        uint32_t p = q.path[idx];
-        Rng rng = rng_make(bi.seed, p % bi.npix, bi.sample0 + p / bi.npix, q.ctr[idx]);
-        Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
-        Best b = closest_hit<COUNT>(S, w, 0.001, RT_INF, L, rng, tally);
-        hb.t[idx] = b.t; hb.ref[idx] = b.ref; hb.chain[idx] = b.chain;
-        q.ctr[idx] = rng.ctr;
+    if (idx < a.n) {
+        RngPos rng;
+        double tmin, tmax;
+        trav_ray_setup(a, idx, rng, tmin, tmax);
+        RaySoA src;
+        src.ox = a.q.ox; src.oy = a.q.oy; src.oz = a.q.oz; src.dx = a.q.dx; src.dy = a.q.dy; src.dz = a.q.dz; src.idx = idx;
+        Best b = closest_hit<COUNT, true>(S, src, tmin, tmax, L, rng, tally);
+        a.hb.t[idx] = b.t; a.hb.ref[idx] = b.ref; a.hb.chain[idx] = b.chain;
+        a.q.ctr[idx] = rng.ctr;
     }
-    if (COUNT) {
-        unsigned long long a = tally.node_tests, b = tally.prim_tests, c = tally.prim_bytes;
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&tallies[0], a); atomicAdd(&tallies[1], b); atomicAdd(&tallies[2], c); }
+    if (COUNT) tally_flush(tally, tallies);
+}
+
+// The same for trees WITH BVH entries, where rays of one wavefront need very different numbers of steps: a fixed
+// grid of wavefronts pulls rays from the queue; each lane runs the per-lane state machine (one tree entry and one
+// primitive test per iteration) and takes the next ray the moment its own is finished, so lanes do not idle
+// waiting for the slowest ray.  Rays are handed out in chunks of RT_CHUNK consecutive queue slots per wavefront
+// (one atomic per chunk).  Every wavefront leaves the loop once the queue is exhausted and its lanes are done.
+#define RT_CHUNK 256u
+#define RT_STEP_THRESHOLD 20
+#define RT_FETCH_THRESHOLD 16
+template <bool COUNT>
+__global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
+                                                                         unsigned long long* tallies) {
+    Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t pool_next = 0, pool_end = 0;
+    bool exhausted = false;
+    uint32_t idx = 0xFFFFFFFFu;
+    Lane ln;
+    ln.cur = ray_world(mk(0, 0, 0), mk(1, 1, 1));
+    ln.cur_chain = 0; ln.i = 0; ln.k = 0; ln.kend = 0; ln.kind = 0; ln.s = 0; ln.e = 0;
+    ln.best.t = RT_INF; ln.best.ref = RT_NO_HIT; ln.best.chain = 0;
+    ln.state = RT_ST_DONE;
+    RngPos rng; rng.k0 = rng.k1 = rng.pixel = rng.sample = rng.ctr = 0;
+    RaySoA src;
+    src.ox = a.q.ox; src.oy = a.q.oy; src.oz = a.q.oz; src.dx = a.q.dx; src.dy = a.q.dy; src.dz = a.q.dz; src.idx = 0;
+    unsigned long long dbg[5] = {0, 0, 0, 0, 0};
+    for (;;) {
+        const bool need = ln.state == RT_ST_DONE;
+        const unsigned long long mask = __ballot(need);
+        int n_node = __popcll(__ballot(ln.state == RT_ST_NODE));
+        int n_run = __popcll(__ballot(ln.state == RT_ST_RUN));
+        // hand out rays only when enough lanes are free (or nobody has work): the hand-out code costs the whole
+        // wavefront its instructions however few lanes it serves
+        if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run == 0)) {
+            if (need && idx != 0xFFFFFFFFu) {
+                a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
+                a.q.ctr[idx] = rng.ctr;
+                idx = 0xFFFFFFFFu;
+            }
+            if (!exhausted) {
+                if (pool_next == pool_end) {
+                    const int leader = __ffsll((long long)mask) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(work, RT_CHUNK);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                    pool_next = base < a.n ? base : a.n;
+                    pool_end = (base + RT_CHUNK) < a.n ? (base + RT_CHUNK) : a.n;
+                    if (base >= a.n) { pool_end = pool_next; exhausted = true; }
+                }
+                if (!exhausted) {
+                    if (need) {
+                        const uint32_t mine = pool_next + (uint32_t)__popcll(mask & lt_mask);
+                        if (mine < pool_end) {
+                            idx = mine;
+                            src.idx = idx;
+                            double tmin, tmax;
+                            trav_ray_setup(a, idx, rng, tmin, tmax);
+                            lane_begin(ln, src, tmin, tmax, L);
+                        }
+                    }
+                    const uint32_t want = pool_next + (uint32_t)__popcll(mask);
+                    pool_next = want < pool_end ? want : pool_end;
+                }
+            }
+            if (exhausted && __ballot(ln.state != RT_ST_DONE) == 0ull) break;
+            n_node = __popcll(__ballot(ln.state == RT_ST_NODE));
+            n_run = __popcll(__ballot(ln.state == RT_ST_RUN));
+        }
+        // Likewise a step runs only when enough lanes are waiting for it, or when it is what most lanes want.
+        const bool do_node = n_node >= RT_STEP_THRESHOLD || n_node >= n_run;
+        const bool do_run = n_run >= RT_STEP_THRESHOLD || n_run > n_node;
+        if (COUNT && lane == 0) { dbg[0]++; dbg[1] += do_node; dbg[2] += do_run; dbg[3] += do_node ? n_node : 0; dbg[4] += do_run ? n_run : 0; }
+        if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT>(S, src, ln, L, rng, tally);
+        if (do_run && ln.state == RT_ST_RUN) lane_prim_step<COUNT>(S, ln, tally);
     }
+    if (COUNT && lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&tallies[3 + k], dbg[k]);
+    if (COUNT) tally_flush(tally, tallies);
+}
+
+// Full HitRecord of every ray of a caller-supplied batch from its closest hit (Hittable::hit's out-parameter).
+__global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8_t* hit, uint32_t* prim, double* t,
+                                 double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Best b; b.t = hb.t[i]; b.ref = hb.ref[i]; b.chain = hb.chain[i];
+    bool h = b.ref != RT_NO_HIT;
+    Rec rec;
+    rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
+    if (h) {
+        Ray w = ray_world(mk(q.ox[i], q.oy[i], q.oz[i]), mk(q.dx[i], q.dy[i], q.dz[i]));
+        rec = finalize<true>(S, w, b);
+    }
+    if (hit) hit[i] = h ? 1 : 0;
+    if (prim) prim[i] = rec.prim_id;
+    if (t) t[i] = h ? b.t : 0.0;
+    if (p3) { p3[3 * i] = rec.p.x; p3[3 * i + 1] = rec.p.y; p3[3 * i + 2] = rec.p.z; }
+    if (n3) { n3[3 * i] = rec.n.x; n3[3 * i + 1] = rec.n.y; n3[3 * i + 2] = rec.n.z; }
+    if (uv2) { uv2[2 * i] = rec.u; uv2[2 * i + 1] = rec.v; }
+    if (front) front[i] = rec.front ? 1 : 0;
+    if (ctr_out) ctr_out[i] = q.ctr[i];
 }
 
 // Material::emitted / scatter on the closest hit, throughput update, termination, and compaction of the
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DScene S, BatchInfo bi, uint32_t n, Queue q, HitBuf hb,
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DScene S, uint64_t seed, uint32_t n, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
-                                                       int last_bounce) {
+                                                       uint32_t iter, uint32_t max_depth) {
     __shared__ uint32_t wave_total[SHADE_BLOCK / 64];
     __shared__ uint32_t block_base;
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool alive = false;
     V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
-    uint32_t p = 0, ctr = 0;
+    uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
     if (idx < n) {
-        p = q.path[idx];
+        slot = q.slot[idx];
+        born = q.born[idx];
         beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
         uint32_t ref = hb.ref[idx];
         if (ref == RT_NO_HIT) {
-            lum_r[p] = beta.x * bgr; lum_g[p] = beta.y * bgg; lum_b[p] = beta.z * bgb;
+            lum_r[slot] = beta.x * bgr; lum_g[slot] = beta.y * bgg; lum_b[slot] = beta.z * bgb;
         } else {
+            pix = q.pix[idx];
+            smp = q.smp[idx];
             Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
             Best b; b.t = hb.t[idx]; b.ref = ref; b.chain = hb.chain[idx];
-            Rec rec = finalize<true>(S, w, b);
-            Rng rng = rng_make(bi.seed, p % bi.npix, bi.sample0 + p / bi.npix, q.ctr[idx]);
+            Rec rec = finalize<false>(S, w, b);
+            Rng rng = rng_make(seed, pix, smp, q.ctr[idx]);
             V3 att, emit;
             const rt_material m = S.mats[rec.mat];
             if (!scatter(S, m, w.d, rec, rng, nd, att, emit)) {
-                lum_r[p] = beta.x * emit.x; lum_g[p] = beta.y * emit.y; lum_b[p] = beta.z * emit.z;
-            } else if (last_bounce) {
+                lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
+            } else if (iter - born + 1u == max_depth) {
                 // the scattered ray would be traced with depth 0: ray_color returns black (camera.rs:350-352)
-                lum_r[p] = 0.0; lum_g[p] = 0.0; lum_b[p] = 0.0;
+                lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;
             } else {
                 beta = beta * att;
                 no = rec.p;
@@ -150,7 +283,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DScene S, BatchInfo bi, u
         out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
         out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
-        out.path[dst] = p;
+        out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
         out.ctr[dst] = ctr;
     }
 }
@@ -179,34 +312,6 @@ __global__ void k_tonemap(const double* film, uint32_t npix, double inv_spp, uin
     for (int c = 0; c < 3; ++c) rgb[3u * pix + c] = to_byte(film[3u * pix + c] * inv_spp);
 }
 
-// Hittable::hit for a batch of caller-supplied rays, full HitRecord out.
-__global__ void __launch_bounds__(TRAV_BLOCK) k_intersect_batch(DScene S, uint64_t seed, const double* o3,
-                                                                const double* d3, const double* tmin,
-                                                                const double* tmax, const uint32_t* rng3, uint64_t n,
-                                                                uint8_t* hit, uint32_t* prim, double* t, double* p3,
-                                                                double* n3, double* uv2, uint8_t* front,
-                                                                uint32_t* ctr_out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
-    Rng rng = rng_make(seed, rng3 ? rng3[3 * i] : (uint32_t)i, rng3 ? rng3[3 * i + 1] : 0u, rng3 ? rng3[3 * i + 2] : 0u);
-    Ray w = ray_world(ld3(o3 + 3 * i), ld3(d3 + 3 * i));
-    Best b = closest_hit<false>(S, w, tmin[i], tmax[i], L, rng, tally);
-    bool h = b.ref != RT_NO_HIT;
-    Rec rec;
-    rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
-    if (h) rec = finalize<true>(S, w, b);
-    if (hit) hit[i] = h ? 1 : 0;
-    if (prim) prim[i] = rec.prim_id;
-    if (t) t[i] = h ? b.t : 0.0;
-    if (p3) { p3[3 * i] = rec.p.x; p3[3 * i + 1] = rec.p.y; p3[3 * i + 2] = rec.p.z; }
-    if (n3) { n3[3 * i] = rec.n.x; n3[3 * i + 1] = rec.n.y; n3[3 * i + 2] = rec.n.z; }
-    if (uv2) { uv2[2 * i] = rec.u; uv2[2 * i + 1] = rec.v; }
-    if (front) front[i] = rec.front ? 1 : 0;
-    if (ctr_out) ctr_out[i] = rng.ctr;
-}
-
 // get_ray + ray_color for chosen (pixel, sample) pairs, one whole path per lane (camera.rs:349-408 as a loop).
 __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_samples(DScene S, rt_camera cam, uint64_t seed,
                                                               uint32_t max_depth, double bgr, double bgg, double bgb,
@@ -222,9 +327,12 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_samples(DScene S, rt_camer
     V3 beta = mk(1.0, 1.0, 1.0), lum = mk(0, 0, 0);
     uint32_t rays = 0;
     for (uint32_t depth = 0; depth < max_depth; ++depth) {
-        Ray w = ray_world(o, d);
+        RayVal src; src.o = o; src.d = d;
+        Ray w = src.world();
         rays++;
-        Best b = closest_hit<false>(S, w, 0.001, RT_INF, L, rng, tally);
+        RngPos rp; rp.k0 = rng.k0; rp.k1 = rng.k1; rp.pixel = rng.pixel; rp.sample = rng.sample; rp.ctr = rng.ctr;
+        Best b = closest_hit<false, false>(S, src, 0.001, RT_INF, L, rp, tally);
+        rng.ctr = rp.ctr;
         if (b.ref == RT_NO_HIT) { lum = beta * mk(bgr, bgg, bgb); break; }
         Rec rec = finalize<true>(S, w, b);
         V3 nd, att, emit;
@@ -270,12 +378,14 @@ struct rt_scene {
     bool committed = false;
     int device = -1;
     uint32_t levels = 0;  // interval slots per lane the walk needs
+    bool has_bvh = false; // selects the traverse kernel: lockstep (no BVH entries) or persistent
+    uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
     std::vector<void*> allocs;
     DScene d;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // render workspace, grown on demand
-    size_t ws_paths = 0;
+    size_t ws_paths = 0, ws_lum = 0;
     std::vector<void*> ws_allocs;
     Queue qa, qb;
     HitBuf hb;
@@ -489,6 +599,8 @@ static int validate(rt_scene* s) {
     while (!open.empty() && open.back().skip == nn) open.pop_back();
     if (!open.empty()) return fail(RT_ERR_INVALID, "unterminated BVH/medium entry");
     s->levels = max_level + 1u;
+    s->has_bvh = false;
+    for (uint32_t i = 0; i < nn; ++i) s->has_bvh |= s->nodes[i].kind == RT_NODE_BVH;
     if (s->levels > RT_MAX_LEVELS) return fail(RT_ERR_LIMIT, "scene needs %u levels, limit %d", s->levels, RT_MAX_LEVELS);
     return RT_OK;
 }
@@ -548,6 +660,15 @@ int rt_scene_commit(rt_scene* s, int device) {
     s->allocs.push_back(s->d_count);
     HIP_TRY(hipMalloc((void**)&s->d_tallies, 64));
     s->allocs.push_back(s->d_tallies);
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false>, TRAV_BLOCK,
+                                                             (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
+        if (per_cu < 1) per_cu = 1;
+        s->persist_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    }
     s->committed = true;
     return RT_OK;
 }
@@ -582,6 +703,23 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 }
 }  // extern "C++"
 
+// One traverse+intersect launch over the rays of `a` on the scene's stream.
+static int launch_traverse(rt_scene* s, const TravArgs& a, bool count) {
+    const size_t lds = levels_lds(s, TRAV_BLOCK);
+    const uint32_t waves = (a.n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    if (!s->has_bvh) {
+        if (count) hipLaunchKernelGGL(k_traverse_lockstep<true>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_tallies);
+        else hipLaunchKernelGGL(k_traverse_lockstep<false>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_tallies);
+    } else {
+        HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
+        const uint32_t grid = std::min(waves, s->persist_waves);
+        if (count) hipLaunchKernelGGL(k_traverse_persistent<true>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_count + 4, s->d_tallies);
+        else hipLaunchKernelGGL(k_traverse_persistent<false>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_count + 4, s->d_tallies);
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
 int rt_intersect_batch(const rt_scene* s_, uint64_t seed, const double* o3, const double* d3, const double* tmin,
                        const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim, double* t,
                        double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out) {
@@ -591,17 +729,30 @@ int rt_intersect_batch(const rt_scene* s_, uint64_t seed, const double* o3, cons
     if (!o3 || !d3 || !tmin || !tmax) return fail(RT_ERR_INVALID, "null ray arrays");
     if (n > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "batch too large");
     HIP_TRY(hipSetDevice(s->device));
+    // rays go through the same queue layout and the same traverse kernel a render uses
+    std::vector<double> soa(6 * n);
+    std::vector<uint32_t> pix(n), smp(n), ctr(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) { soa[c * n + i] = o3[3 * i + c]; soa[(3 + c) * n + i] = d3[3 * i + c]; }
+        pix[i] = rng3 ? rng3[3 * i] : (uint32_t)i;
+        smp[i] = rng3 ? rng3[3 * i + 1] : 0u;
+        ctr[i] = rng3 ? rng3[3 * i + 2] : 0u;
+    }
     std::vector<void*> tmp;
     int rc = RT_OK;
-    double *d_o, *d_d, *d_tmin, *d_tmax, *d_t, *d_p, *d_n, *d_uv;
-    uint32_t *d_rng, *d_prim, *d_ctr;
+    double *d_soa, *d_tmin, *d_tmax, *d_t, *d_p, *d_n, *d_uv, *d_ht;
+    uint32_t *d_pix, *d_smp, *d_ctr, *d_prim, *d_cout, *d_href, *d_hchain;
     uint8_t *d_hit, *d_front;
     do {
-        if ((rc = dev_copy_in(tmp, o3, 3 * n, &d_o))) break;
-        if ((rc = dev_copy_in(tmp, d3, 3 * n, &d_d))) break;
+        if ((rc = dev_copy_in(tmp, soa.data(), 6 * n, &d_soa))) break;
         if ((rc = dev_copy_in(tmp, tmin, n, &d_tmin))) break;
         if ((rc = dev_copy_in(tmp, tmax, n, &d_tmax))) break;
-        if ((rc = dev_copy_in(tmp, rng3, 3 * n, &d_rng))) break;
+        if ((rc = dev_copy_in(tmp, pix.data(), n, &d_pix))) break;
+        if ((rc = dev_copy_in(tmp, smp.data(), n, &d_smp))) break;
+        if ((rc = dev_copy_in(tmp, ctr.data(), n, &d_ctr))) break;
+        if ((rc = dev_alloc(tmp, true, n, &d_ht))) break;
+        if ((rc = dev_alloc(tmp, true, n, &d_href))) break;
+        if ((rc = dev_alloc(tmp, true, n, &d_hchain))) break;
         if ((rc = dev_alloc(tmp, hit != nullptr, n, &d_hit))) break;
         if ((rc = dev_alloc(tmp, prim != nullptr, n, &d_prim))) break;
         if ((rc = dev_alloc(tmp, t != nullptr, n, &d_t))) break;
@@ -609,16 +760,25 @@ int rt_intersect_batch(const rt_scene* s_, uint64_t seed, const double* o3, cons
         if ((rc = dev_alloc(tmp, n3 != nullptr, 3 * n, &d_n))) break;
         if ((rc = dev_alloc(tmp, uv2 != nullptr, 2 * n, &d_uv))) break;
         if ((rc = dev_alloc(tmp, front != nullptr, n, &d_front))) break;
-        if ((rc = dev_alloc(tmp, ctr_out != nullptr, n, &d_ctr))) break;
-        uint32_t grid = (uint32_t)((n + TRAV_BLOCK - 1) / TRAV_BLOCK);
-        hipLaunchKernelGGL(k_intersect_batch, dim3(grid), dim3(TRAV_BLOCK), levels_lds(s, TRAV_BLOCK), s->stream, s->d,
-                           seed, d_o, d_d, d_tmin, d_tmax, d_rng, n, d_hit, d_prim, d_t, d_p, d_n, d_uv, d_front, d_ctr);
+        if ((rc = dev_alloc(tmp, ctr_out != nullptr, n, &d_cout))) break;
+        TravArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.q.ox = d_soa; a.q.oy = d_soa + n; a.q.oz = d_soa + 2 * n;
+        a.q.dx = d_soa + 3 * n; a.q.dy = d_soa + 4 * n; a.q.dz = d_soa + 5 * n;
+        a.q.pix = d_pix; a.q.smp = d_smp; a.q.ctr = d_ctr;
+        a.hb.t = d_ht; a.hb.ref = d_href; a.hb.chain = d_hchain;
+        a.seed = seed;
+        a.n = (uint32_t)n;
+        a.tmin = d_tmin; a.tmax = d_tmax;
+        if ((rc = launch_traverse(s, a, false))) break;
+        hipLaunchKernelGGL(k_finalize_batch, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, s->d, a.q, a.hb,
+                           (uint32_t)n, d_hit, d_prim, d_t, d_p, d_n, d_uv, d_front, d_cout);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-        if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, "intersect kernel: %s", hipGetErrorString(e)); break; }
+        if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, "intersect kernels: %s", hipGetErrorString(e)); break; }
 #define BACK(hostp, devp, cnt) if (hostp && hipMemcpy(hostp, devp, (cnt) * sizeof(*hostp), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(RT_ERR_DEVICE, "copy back failed"); break; }
         BACK(hit, d_hit, n); BACK(prim, d_prim, n); BACK(t, d_t, n); BACK(p3, d_p, 3 * n); BACK(n3, d_n, 3 * n);
-        BACK(uv2, d_uv, 2 * n); BACK(front, d_front, n); BACK(ctr_out, d_ctr, n);
+        BACK(uv2, d_uv, 2 * n); BACK(front, d_front, n); BACK(ctr_out, d_cout, n);
 #undef BACK
     } while (0);
     free_list(tmp);
@@ -631,24 +791,29 @@ static int ws_queue(rt_scene* s, Queue& q, size_t n) {
         HIP_TRY(hipMalloc((void**)pp, n * sizeof(double)));
         s->ws_allocs.push_back(*pp);
     }
-    HIP_TRY(hipMalloc((void**)&q.path, n * sizeof(uint32_t))); s->ws_allocs.push_back(q.path);
-    HIP_TRY(hipMalloc((void**)&q.ctr, n * sizeof(uint32_t))); s->ws_allocs.push_back(q.ctr);
+    uint32_t** g[5] = {&q.pix, &q.smp, &q.slot, &q.born, &q.ctr};
+    for (auto pp : g) {
+        HIP_TRY(hipMalloc((void**)pp, n * sizeof(uint32_t)));
+        s->ws_allocs.push_back(*pp);
+    }
     return RT_OK;
 }
-static int ensure_workspace(rt_scene* s, size_t paths) {
-    if (s->ws_paths >= paths) return RT_OK;
+static int ensure_workspace(rt_scene* s, size_t paths, size_t lum) {
+    if (s->ws_paths >= paths && s->ws_lum >= lum) return RT_OK;
     free_list(s->ws_allocs);
     s->ws_paths = 0;
+    s->ws_lum = 0;
     int rc;
     if ((rc = ws_queue(s, s->qa, paths))) return rc;
     if ((rc = ws_queue(s, s->qb, paths))) return rc;
     HIP_TRY(hipMalloc((void**)&s->hb.t, paths * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
     HIP_TRY(hipMalloc((void**)&s->hb.ref, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
     HIP_TRY(hipMalloc((void**)&s->hb.chain, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
-    HIP_TRY(hipMalloc((void**)&s->lum_r, paths * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
-    HIP_TRY(hipMalloc((void**)&s->lum_g, paths * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
-    HIP_TRY(hipMalloc((void**)&s->lum_b, paths * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
+    HIP_TRY(hipMalloc((void**)&s->lum_r, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
+    HIP_TRY(hipMalloc((void**)&s->lum_g, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
+    HIP_TRY(hipMalloc((void**)&s->lum_b, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
     s->ws_paths = paths;
+    s->ws_lum = lum;
     return RT_OK;
 }
 
@@ -661,6 +826,12 @@ static int check_render_args(const rt_scene* s, const rt_camera* cam, const rt_r
     return RT_OK;
 }
 
+// Streaming wavefront schedule.  Samples are generated in batches of `spb` samples of every pixel.  One iteration =
+// one traverse launch + one shade launch over ALL paths in flight, whatever their depth; whenever the queue has room
+// the next batch is appended, so launches stay large while old paths die off (a launch over a nearly empty queue
+// costs as much as its slowest ray).  A batch's radiances land in its own section of the luminance buffer and are
+// added to the film, batch after batch and sample after sample, once the batch is `max_depth` iterations old or
+// nothing is in flight: the film is the same in-order sum whatever the queue size.
 int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, void* film_dev,
                      rt_stats* stats) {
     rt_scene* s = const_cast<rt_scene*>(s_);
@@ -674,45 +845,51 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     rt_stats st;
     std::memset(&st, 0, sizeof st);
     const bool count = (o->flags & RT_FLAG_COUNTERS) != 0;
-
-    uint64_t want = o->batch_paths ? o->batch_paths : (16ull << 20);
-    uint32_t spb = (uint32_t)std::max<uint64_t>(1, want / npix);  // samples per batch
-    spb = std::min<uint32_t>(spb, std::max<uint32_t>(o->spp_count, 1u));
-    if ((uint64_t)spb * npix > 0x7FFFFFFFull) spb = (uint32_t)(0x7FFFFFFFull / npix);
-    if ((rc = ensure_workspace(s, (size_t)spb * npix))) return rc;
-
     hipStream_t sm = s->stream;
     HIP_TRY(hipEventRecord(s->ev[0], sm));
-    hipLaunchKernelGGL(k_fill, dim3((3u * npix + 255u) / 256u), dim3(256), 0, sm, film, (size_t)3 * npix, -0.0);
-    if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 24, sm));
-    const size_t lds = levels_lds(s, TRAV_BLOCK);
+    hipLaunchKernelGGL(k_fill, dim3((3u * npix + 255u) / 256u), dim3(256), 0, sm, film, (size_t)3 * npix,
+                       (o->max_depth == 0 && o->spp_count > 0) ? 0.0 : -0.0);
+    if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 64, sm));
 
-    for (uint32_t s0 = 0; s0 < o->spp_count; s0 += spb) {
-        uint32_t ns = std::min(spb, o->spp_count - s0);
-        uint32_t n = ns * npix;
-        BatchInfo bi;
-        bi.npix = npix; bi.width = cam->width; bi.sample0 = o->spp_begin + s0; bi.seed = o->seed;
-        st.paths += n;
+    if (o->max_depth > 0 && o->spp_count > 0) {
+        const uint64_t qcap_want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (32ull << 20), npix);
+        uint32_t spb = (uint32_t)std::max<uint64_t>(1, (qcap_want / 4) / npix);  // samples per batch
+        spb = std::min(spb, o->spp_count);
+        const uint64_t bsize = (uint64_t)spb * npix;                      // paths per full batch
+        const uint64_t qcap = std::max<uint64_t>(qcap_want, bsize);
+        const uint32_t nbatches = (o->spp_count + spb - 1) / spb;
+        const uint32_t nslots = std::min<uint32_t>(o->max_depth + 1u, nbatches);
+        if (qcap > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
+        if ((rc = ensure_workspace(s, (size_t)qcap, (size_t)(bsize * nslots)))) return rc;
+        std::vector<uint32_t> born_at(nbatches, 0);
         Queue qin = s->qa, qout = s->qb;
-        if (o->max_depth == 0) {
-            HIP_TRY(hipMemsetAsync(s->lum_r, 0, (size_t)n * 8, sm));
-            HIP_TRY(hipMemsetAsync(s->lum_g, 0, (size_t)n * 8, sm));
-            HIP_TRY(hipMemsetAsync(s->lum_b, 0, (size_t)n * 8, sm));
-        } else {
-            hipLaunchKernelGGL(k_raygen, dim3((n + TRAV_BLOCK - 1) / TRAV_BLOCK), dim3(TRAV_BLOCK), 0, sm, *cam, bi, n, qin);
-        }
-        for (uint32_t bounce = 0; bounce < o->max_depth && n > 0; ++bounce) {
+        uint32_t n = 0, iter = 0, injected = 0, accumulated = 0;
+        auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
+        for (;;) {
+            if (injected < nbatches && (uint64_t)n + bsize <= qcap) {
+                // a slot is reused only after its previous batch has been added to the film
+                if (injected >= nslots && accumulated + nslots <= injected) return fail(RT_ERR_STATE, "luminance slot still in use");
+                const uint32_t ns = batch_samples(injected), nb = ns * npix;
+                const uint32_t slot0 = (uint32_t)((injected % nslots) * bsize);
+                hipLaunchKernelGGL(k_raygen, dim3((nb + 255u) / 256u), dim3(256), 0, sm, *cam, o->seed, npix,
+                                   o->spp_begin + injected * spb, nb, n, slot0, iter, qin);
+                born_at[injected] = iter;
+                injected++;
+                n += nb;
+                st.paths += nb;
+            }
+            if (n == 0) break;  // nothing in flight and nothing left to inject
             st.rays += n;
-            st.bounces = std::max(st.bounces, bounce + 1);
             HIP_TRY(hipMemsetAsync(s->d_count, 0, 4, sm));
             HIP_TRY(hipEventRecord(s->ev[1], sm));
-            uint32_t tg = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
-            if (count) hipLaunchKernelGGL(k_traverse<true>, dim3(tg), dim3(TRAV_BLOCK), lds, sm, s->d, bi, n, qin, s->hb, s->d_tallies);
-            else hipLaunchKernelGGL(k_traverse<false>, dim3(tg), dim3(TRAV_BLOCK), lds, sm, s->d, bi, n, qin, s->hb, s->d_tallies);
+            TravArgs ta;
+            std::memset(&ta, 0, sizeof ta);
+            ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.n = n;
+            if ((rc = launch_traverse(s, ta, count))) return rc;
             HIP_TRY(hipEventRecord(s->ev[2], sm));
-            hipLaunchKernelGGL(k_shade, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, s->d, bi, n, qin,
-                               s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], o->background[1],
-                               o->background[2], (bounce + 1 == o->max_depth) ? 1 : 0);
+            hipLaunchKernelGGL(k_shade, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, s->d, o->seed, n,
+                               qin, s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0],
+                               o->background[1], o->background[2], iter, o->max_depth);
             HIP_TRY(hipEventRecord(s->ev[3], sm));
             HIP_TRY(hipMemcpyAsync(s->h_count, s->d_count, 4, hipMemcpyDeviceToHost, sm));
             HIP_TRY(hipStreamSynchronize(sm));
@@ -720,13 +897,22 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
             st.ms_traverse += ms;
+            if (getenv("RT_DEBUG_BOUNCES")) fprintf(stderr, "iter %u n %u traverse_ms %.3f Mrays/s %.0f\n", iter, n, ms, n / ms / 1e3);
             HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
             st.ms_shade += ms;
             st.traverse_launches++;
             n = *s->h_count;
             std::swap(qin, qout);
+            iter++;
+            // batches whose paths are all finished go to the film, oldest first
+            while (accumulated < injected && (n == 0 || iter - born_at[accumulated] >= o->max_depth)) {
+                const uint32_t slot0 = (uint32_t)((accumulated % nslots) * bsize);
+                hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + slot0,
+                                   s->lum_g + slot0, s->lum_b + slot0, npix, batch_samples(accumulated), film);
+                accumulated++;
+            }
         }
-        hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r, s->lum_g, s->lum_b, npix, ns, film);
+        st.bounces = std::min(iter, o->max_depth);
     }
     HIP_TRY(hipEventRecord(s->ev[3], sm));
     HIP_TRY(hipStreamSynchronize(sm));
@@ -735,8 +921,11 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[3]));
     st.ms_total = ms;
     if (count) {
-        unsigned long long h[3];
-        HIP_TRY(hipMemcpy(h, s->d_tallies, 24, hipMemcpyDeviceToHost));
+        unsigned long long h[8];
+        HIP_TRY(hipMemcpy(h, s->d_tallies, 64, hipMemcpyDeviceToHost));
+        if (getenv("RT_DEBUG"))
+            fprintf(stderr, "dbg rays %llu iters %llu node_steps %llu run_steps %llu node_lanes %llu run_lanes %llu node_tests %llu prim_tests %llu\n",
+                    (unsigned long long)st.rays, h[3], h[4], h[5], h[6], h[7], h[0], h[1]);
         st.node_tests = h[0];
         st.prim_tests = h[1];
         st.prim_bytes = h[2];

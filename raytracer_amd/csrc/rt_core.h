@@ -74,21 +74,14 @@ RT_HD Rng rng_make(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t ctr)
     r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
     return r;
 }
-RT_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * b) >> 32);
-#endif
-}
 RT_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = mulhi32(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        uint32_t hi1 = mulhi32(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        uint32_t n0 = hi1 ^ c[1] ^ k0;
-        uint32_t n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];  // one 32x32->64 multiply each
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -114,9 +107,22 @@ RT_HD V3 random_unit_vector(Rng& r) {  // point3/mod.rs:229-250
         if (len2(p) < 1.0) return unit(p);
     }
 }
+// One draw at position (pixel, sample, ctr) without carrying a cached block around (the tree walk draws at most
+// once per medium and must stay light on registers).
+RT_HD double rng_draw_at(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t ctr) {
+    uint32_t w[4] = {pixel, sample, ctr >> 1, 0u};
+    philox4x32_10(w, k0, k1);
+    uint64_t bits = (ctr & 1u) ? (((uint64_t)w[3] << 32) | w[2]) : (((uint64_t)w[1] << 32) | w[0]);
+    return (double)(bits >> 12) * (1.0 / 4503599627370496.0);
+}
+struct RngPos {  // what the walk needs of a path's random stream
+    uint32_t k0, k1, pixel, sample, ctr;
+};
 
 // ------------------------------------------------------------------------------------------------------------
-// Scene as the kernels see it: per-type arrays of packed f64 records plus the flattened tree.
+// Scene as the kernels see it: per-type arrays of packed f64 records plus the flattened tree.  Every record array
+// starts 16-byte aligned and every record is a whole number of 16-byte pairs, so records are fetched as double2
+// (one 16-byte load per pair; a quad or triangle is exactly one 128-byte line).
 struct DScene {
     const rt_node* nodes;
     uint32_t n_nodes;
@@ -135,10 +141,21 @@ struct DScene {
     const rt_material* mats;
     const rt_texture* texs;
     const uint8_t* texels;        // all images back to back
-    const uint32_t* image_desc;   // per slot: byte offset/3 (pixel offset), width, height
+    const uint32_t* image_desc;   // per slot: first pixel, width, height
     const double* perlin_vec;     // per slot 256*3
     const uint32_t* perlin_perm;  // per slot 3*256
 };
+
+struct Node {  // rt_node unpacked
+    uint32_t kind, level, chain, skip, first, count;
+};
+RT_HD Node load_node(const DScene& S, uint32_t i) {
+    const uint4 raw = reinterpret_cast<const uint4*>(S.nodes)[i];
+    Node n;
+    n.kind = raw.x & 0xFFu; n.level = (raw.x >> 8) & 0xFFu; n.chain = raw.x >> 16;
+    n.skip = raw.y; n.first = raw.z; n.count = raw.w;
+    return n;
+}
 
 struct Ray {  // src/ray.rs:4-8; `a` caches direction.length_squared()
     V3 o, d, inv;
@@ -180,6 +197,21 @@ RT_HD Ray ray_in_chain(const DScene& S, const Ray& w, uint32_t chain) {
     }
     return r;
 }
+// Where a lane re-reads its world-space ray from when the walk changes chain (kept out of registers meanwhile).
+struct RaySoA {  // path queue
+    const double *ox, *oy, *oz, *dx, *dy, *dz;
+    uint32_t idx;
+    RT_HD Ray world() const { return ray_world(mk(ox[idx], oy[idx], oz[idx]), mk(dx[idx], dy[idx], dz[idx])); }
+};
+struct RayAoS {  // caller-supplied batches, 3 f64 per ray
+    const double *o3, *d3;
+    uint64_t i;
+    RT_HD Ray world() const { return ray_world(ld3(o3 + 3 * i), ld3(d3 + 3 * i)); }
+};
+struct RayVal {
+    V3 o, d;
+    RT_HD Ray world() const { return ray_world(o, d); }
+};
 
 // Per-lane array of ray intervals, one slot per nesting level of BVH / medium entries.  `stride` is the number
 // of lanes sharing the backing store (LDS on the device: slot l of lane i lives at base[l * stride + i]).
@@ -202,20 +234,35 @@ struct Tally {
     uint32_t node_tests, prim_tests, prim_bytes;
 };
 
+// True when every active lane of the wavefront holds the same x (returned in `first`).  Records addressed through
+// `first` are then fetched once per wavefront with scalar loads instead of once per lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD uint32_t wave_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+RT_HD bool wave_uniform(uint32_t x, uint32_t& first) {
+    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+    return __all(x == first) != 0;
+}
+#else
+inline bool& host_uniform_mode() { static bool m = true; return m; }  // lets CPU tests take either branch
+RT_HD uint32_t wave_first(uint32_t x) { return x; }
+RT_HD bool wave_uniform(uint32_t x, uint32_t& first) { first = x; return host_uniform_mode(); }
+#endif
+
 // AABB::hit, aabb.rs:164-200: narrows (s, e) axis by axis, miss as soon as e <= s.
-RT_HD bool slab(const double* b, const Ray& r, double& s, double& e) {
+RT_HD bool slab(const double2* b, const Ray& r, double& s, double& e) {
+    const double2 bx = b[0], by = b[1], bz = b[2];
     {
-        double t0 = (b[0] - r.o.x) * r.inv.x, t1 = (b[1] - r.o.x) * r.inv.x;
+        double t0 = (bx.x - r.o.x) * r.inv.x, t1 = (bx.y - r.o.x) * r.inv.x;
         if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
         if (e <= s) return false;
     }
     {
-        double t0 = (b[2] - r.o.y) * r.inv.y, t1 = (b[3] - r.o.y) * r.inv.y;
+        double t0 = (by.x - r.o.y) * r.inv.y, t1 = (by.y - r.o.y) * r.inv.y;
         if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
         if (e <= s) return false;
     }
     {
-        double t0 = (b[4] - r.o.z) * r.inv.z, t1 = (b[5] - r.o.z) * r.inv.z;
+        double t0 = (bz.x - r.o.z) * r.inv.z, t1 = (bz.y - r.o.z) * r.inv.z;
         if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
         if (e <= s) return false;
     }
@@ -223,10 +270,11 @@ RT_HD bool slab(const double* b, const Ray& r, double& s, double& e) {
 }
 
 // Sphere::hit, sphere.rs:40-63 (the part that decides t; the record is rebuilt in finalize()).
-RT_HD bool sphere_t(const double* sp, const Ray& r, double s, double e, double& t) {
-    V3 oc = mk(sp[0], sp[1], sp[2]) - r.o;
+RT_HD bool sphere_t(const double2* sp, const Ray& r, double s, double e, double& t) {
+    const double2 a0 = sp[0], a1 = sp[1];
+    V3 oc = mk(a0.x, a0.y, a1.x) - r.o;
     double h = dot(oc, r.d);
-    double c = len2(oc) - sp[3] * sp[3];
+    double c = len2(oc) - a1.y * a1.y;
     double disc = h * h - r.a * c;
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
@@ -238,31 +286,61 @@ RT_HD bool sphere_t(const double* sp, const Ray& r, double s, double e, double& 
     t = root;
     return true;
 }
+// The 16-f64 record of a quad or triangle: n(3) d q(3) u(3) v(3) w(3).
+struct Planar {
+    V3 n, q, u, v, w;
+    double d;
+};
+RT_HD Planar load_planar(const double2* p) {
+    const double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
+    Planar r;
+    r.n = mk(a0.x, a0.y, a1.x); r.d = a1.y;
+    r.q = mk(a2.x, a2.y, a3.x);
+    r.u = mk(a3.y, a4.x, a4.y);
+    r.v = mk(a5.x, a5.y, a6.x);
+    r.w = mk(a6.y, a7.x, a7.y);
+    return r;
+}
 // Parallelogram::hit, parallelogram.rs:96-120: closed interval, tested before the parallel check.
-RT_HD bool quad_t(const double* q, const Ray& r, double s, double e, double& t_out) {
-    V3 n = ld3(q);
-    double den = dot(n, r.d);
-    double t = (q[3] - dot(n, r.o)) / den;
+RT_HD bool quad_t(const Planar& g, const Ray& r, double s, double e, double& t_out) {
+    double den = dot(g.n, r.d);
+    double t = (g.d - dot(g.n, r.o)) / den;
     if (e < t || t < s) return false;
     if (fabs(den) < 1e-8) return false;
-    V3 ph = ray_at(r, t) - ld3(q + 4);
-    double alpha = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
-    double beta = dot(ld3(q + 13), cross(ld3(q + 7), ph));
+    V3 ph = ray_at(r, t) - g.q;
+    double alpha = dot(g.w, cross(ph, g.v));
+    double beta = dot(g.w, cross(g.u, ph));
     if (!(0.0 <= alpha && alpha < 1.0 && 0.0 <= beta && beta < 1.0)) return false;  // :139-143
     t_out = t;
     return true;
 }
 // Triangle::hit, triangle.rs:123-144: parallel check first, half-open interval, strict barycentric test.
-RT_HD bool tri_t(const double* q, const Ray& r, double s, double e, double& t_out) {
-    V3 n = ld3(q);
-    double den = dot(n, r.d);
+RT_HD bool tri_t(const Planar& g, const Ray& r, double s, double e, double& t_out) {
+    double den = dot(g.n, r.d);
     if (fabs(den) < 1e-8) return false;
-    double t = (q[3] - dot(n, r.o)) / den;
+    double t = (g.d - dot(g.n, r.o)) / den;
     if (!(s <= t && t < e)) return false;
-    V3 ph = ray_at(r, t) - ld3(q + 4);
-    double alpha = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
-    double beta = dot(ld3(q + 13), cross(ld3(q + 7), ph));
+    V3 ph = ray_at(r, t) - g.q;
+    double alpha = dot(g.w, cross(ph, g.v));
+    double beta = dot(g.w, cross(g.u, ph));
     if (!(alpha > 0.0 && beta > 0.0 && alpha + beta < 1.0)) return false;  // :163-165
+    t_out = t;
+    return true;
+}
+// Both of the above in one instruction stream, for wavefronts whose lanes hold a mix of quads and triangles.  The
+// two hit() bodies differ only in the order of the interval and parallel checks (either rejects, so the order does
+// not show in the result), in the interval being closed or half-open, and in the interior test.
+RT_HD bool planar_t(const Planar& g, bool is_tri, const Ray& r, double s, double e, double& t_out) {
+    double den = dot(g.n, r.d);
+    double t = (g.d - dot(g.n, r.o)) / den;
+    bool in_iv = is_tri ? (s <= t && t < e) : !(e < t || t < s);
+    if (fabs(den) < 1e-8 || !in_iv) return false;
+    V3 ph = ray_at(r, t) - g.q;
+    double alpha = dot(g.w, cross(ph, g.v));
+    double beta = dot(g.w, cross(g.u, ph));
+    bool inside = is_tri ? (alpha > 0.0 && beta > 0.0 && alpha + beta < 1.0)
+                         : (0.0 <= alpha && alpha < 1.0 && 0.0 <= beta && beta < 1.0);
+    if (!inside) return false;
     t_out = t;
     return true;
 }
@@ -271,12 +349,13 @@ RT_HD V3 prod1(V3 u, V3 v) { return mk(u.x * v.y, u.x * v.z, u.y * v.z); }  // :
 RT_HD V3 anticross(V3 u, V3 v) {                                            // :99-105
     return mk(u.x * v.y + u.y * v.x, u.x * v.z + u.z * v.x, u.y * v.z + u.z * v.y);
 }
-RT_HD bool quadric_t(const double* q, const Ray& r, double s, double e, double& t) {
-    V3 p1 = ld3(q), p2 = ld3(q + 3), p3 = ld3(q + 6);
+RT_HD bool quadric_t(const double2* q, const Ray& r, double s, double e, double& t) {
+    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+    V3 p1 = mk(a0.x, a0.y, a1.x), p2 = mk(a1.y, a2.x, a2.y), p3 = mk(a3.x, a3.y, a4.x);
     V3 o = r.o, d = r.d;
     double a = dot(p1, d * d) + dot(p2, prod1(d, d));
     double h = -dot(p1, d * o) - 0.5 * dot(p2, anticross(d, o)) - 0.5 * dot(p3, d);
-    double c = dot(p1, o * o) + dot(p2, anticross(o, o)) + dot(p3, o) + q[9];
+    double c = dot(p1, o * o) + dot(p2, anticross(o, o)) + dot(p3, o) + a4.y;
     double disc = h * h - a * c;
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
@@ -289,132 +368,265 @@ RT_HD bool quadric_t(const double* q, const Ray& r, double s, double e, double& 
     return true;
 }
 
+// One run of `count` primitives of one type, in list order, against the interval (s, e): HittableSlice::hit
+// (hittable_list.rs:88-102) with closest_so_far kept in e.
+template <bool COUNT>
+RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t count, uint32_t chain, const Ray& cur,
+                     double s, double e, Best& best, Tally& tally) {
+    const uint32_t last = first + count;
+    if (kind == RT_NODE_TRIANGLES) {
+        const double2* base = reinterpret_cast<const double2*>(S.tris);
+        for (uint32_t k = first; k < last; ++k) {
+            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+            double t;
+            if (tri_t(load_planar(base + 8u * k), cur, s, e, t)) {
+                best.t = t; best.ref = make_ref(RT_NODE_TRIANGLES, k); best.chain = chain;
+                e = t;  // t < e already
+            }
+        }
+    } else if (kind == RT_NODE_QUADS) {
+        const double2* base = reinterpret_cast<const double2*>(S.quads);
+        for (uint32_t k = first; k < last; ++k) {
+            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+            double t;
+            if (quad_t(load_planar(base + 8u * k), cur, s, e, t)) {
+                best.t = t; best.ref = make_ref(RT_NODE_QUADS, k); best.chain = chain;
+                e = t;  // t <= e already: a later quad at the same t replaces an earlier one
+            }
+        }
+    } else if (kind == RT_NODE_SPHERES) {
+        const double2* base = reinterpret_cast<const double2*>(S.spheres);
+        for (uint32_t k = first; k < last; ++k) {
+            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 40u; }
+            double t;
+            if (sphere_t(base + 2u * k, cur, s, e, t)) {
+                best.t = t; best.ref = make_ref(RT_NODE_SPHERES, k); best.chain = chain;
+                e = t;
+            }
+        }
+    } else {  // RT_NODE_QUADRICS
+        const double2* base = reinterpret_cast<const double2*>(S.quadrics);
+        for (uint32_t k = first; k < last; ++k) {
+            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
+            double t;
+            if (quadric_t(base + 5u * k, cur, s, e, t)) {
+                best.t = t; best.ref = make_ref(RT_NODE_QUADRICS, k); best.chain = chain;
+                e = t;
+            }
+        }
+    }
+}
+
+// BVHNode::hit's box test (bvh.rs:31-37) for the entry `n` at index i: returns the index to go on with.
+template <bool COUNT>
+RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels& L, const Best& best, Ray& cur,
+                        Tally& tally) {
+    if (COUNT) tally.node_tests++;
+    ray_need_inv(cur);
+    double2 iv = lv_get(L, n.level);
+    double s = iv.x, e = fmin(iv.y, best.t);
+    if (slab(reinterpret_cast<const double2*>(S.boxes) + 3u * n.first, cur, s, e)) {
+        lv_set(L, n.level + 1u, s, e);
+        return i + 1u;
+    }
+    return n.skip;
+}
+
 // Walks entries [i, iend) of the flattened tree in order, which is the order of the reference's recursion:
 // HittableSlice::hit in list order with the interval end shrunk to the closest hit so far
 // (hittable_list.rs:88-102), BVHNode::hit narrowing the interval by its box and handing it to left, then right
 // with end = left's t (bvh.rs:29-60).  The interval an entry sees is (start, min(end, best.t)) of its level: a
 // minimum over nested narrowings does not depend on when each was taken, so this equals the value the recursion
 // passes down.  MEDIA selects whether ConstantMedium entries may occur (not inside a medium's own boundary).
-template <bool MEDIA, bool COUNT>
-RT_HD void walk(const DScene& S, const Ray& wray, uint32_t i, uint32_t iend, const Levels& L, Rng& rng, Best& best,
+//
+// Shape of the loop: every lane first runs through BVH entries until it stands on a primitive run (or a medium),
+// then all lanes work on their runs together; lanes that stand on the same entry take the scalar-load branch.
+//
+// LOCKSTEP = true is for trees without BVH entries: every lane then visits the same entries in the same order, so
+// the per-lane branches are dropped and all scene data comes through scalar loads.
+template <bool MEDIA, bool COUNT, bool LOCKSTEP, class Src>
+RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, const Levels& L, RngPos& rng, Best& best,
                 Ray& cur, uint32_t& cur_chain, Tally& tally) {
-    while (i < iend) {
-        const rt_node n = S.nodes[i];
-        if (n.chain != cur_chain) {
-            cur = ray_in_chain(S, wray, n.chain);
-            cur_chain = n.chain;
+    for (;;) {
+        Node n;
+        n.kind = RT_NODE_BVH; n.level = 0; n.chain = 0; n.skip = 0; n.first = 0; n.count = 0;
+        bool have = false;
+        while (i < iend) {
+            uint32_t i0;
+            if (LOCKSTEP || wave_uniform(i, i0)) {
+                if (LOCKSTEP) i0 = wave_first(i);
+                const Node nu = load_node(S, i0);
+                if (nu.kind != RT_NODE_BVH) { n = nu; have = true; break; }
+                if (nu.chain != cur_chain) { cur = ray_in_chain(S, src.world(), nu.chain); cur_chain = nu.chain; }
+                i = bvh_step<COUNT>(S, nu, i0, L, best, cur, tally);
+            } else {
+                const Node nl = load_node(S, i);
+                if (nl.kind != RT_NODE_BVH) { n = nl; have = true; break; }
+                if (nl.chain != cur_chain) { cur = ray_in_chain(S, src.world(), nl.chain); cur_chain = nl.chain; }
+                i = bvh_step<COUNT>(S, nl, i, L, best, cur, tally);
+            }
         }
-        double2 iv = lv_get(L, n.level);
-        double s = iv.x;
-        double e = fmin(iv.y, best.t);
-        switch (n.kind) {
-            case RT_NODE_BVH: {
-                if (COUNT) tally.node_tests++;
-                ray_need_inv(cur);
-                if (slab(S.boxes + 6u * n.first, cur, s, e)) {
-                    lv_set(L, n.level + 1u, s, e);
-                    i = i + 1u;
-                } else {
-                    i = n.skip;
+        if (!have) break;
+        if (n.chain != cur_chain) { cur = ray_in_chain(S, src.world(), n.chain); cur_chain = n.chain; }
+        const double2 iv = lv_get(L, n.level);
+        const double s = iv.x, e = fmin(iv.y, best.t);
+        if (n.kind == RT_NODE_MEDIUM) {
+            if constexpr (MEDIA) {
+                // ConstantMedium::hit, constant_medium.rs:46-93
+                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
+                const rt_medium m = S.media[n.first];
+                const double ray_length = sqrt(cur.a);  // of the ray the medium itself receives
+                double t1 = 0.0, t2 = 0.0, lo = -RT_INF;
+                bool ok = true;
+                for (int pass = 0; pass < 2 && ok; ++pass) {
+                    Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
+                    lv_set(L, n.level + 1u, lo, RT_INF);
+                    walk<false, COUNT, LOCKSTEP>(S, src, i + 1u, n.skip, L, rng, b, cur, cur_chain, tally);
+                    ok = b.ref != RT_NO_HIT;
+                    if (pass == 0) t1 = b.t; else t2 = b.t;
+                    lo = b.t + 0.0001;
                 }
-                break;
-            }
-            case RT_NODE_SPHERES: {
-                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 40u; }
-                    double t;
-                    if (sphere_t(S.spheres + 4u * k, cur, s, e, t)) {
-                        best.t = t; best.ref = make_ref(RT_NODE_SPHERES, k); best.chain = n.chain;
-                        e = t;  // t < e already
+                if (ok) {
+                    t1 = fmax(t1, s);
+                    t2 = fmin(t2, e);
+                    t1 = fmax(t1, 0.0);
+                    double inside = (t2 - t1) * ray_length;
+                    double x = rng_draw_at(rng.k0, rng.k1, rng.pixel, rng.sample, rng.ctr) * (1.0 - 0.0) + 0.0;
+                    rng.ctr++;
+                    double hit_distance = m.neg_inv_density * log(x);
+                    if (!(hit_distance > inside)) {
+                        best.t = t1 + hit_distance / ray_length;
+                        best.ref = make_ref(RT_NODE_MEDIUM, n.first);
+                        best.chain = n.chain;
                     }
                 }
-                i = i + 1u;
-                break;
             }
-            case RT_NODE_QUADS: {
-                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
-                    double t;
-                    if (quad_t(S.quads + 16u * k, cur, s, e, t)) {
-                        best.t = t; best.ref = make_ref(RT_NODE_QUADS, k); best.chain = n.chain;
-                        e = t;  // t <= e already
-                    }
-                }
-                i = i + 1u;
-                break;
+            i = n.skip;
+        } else {
+            uint32_t i0;
+            if (LOCKSTEP || wave_uniform(i, i0)) {
+                if (LOCKSTEP) i0 = wave_first(i);
+                // all lanes stand on the same run (top-level lists, shared leaves): the entry and its records are
+                // addressed by a wavefront-uniform index and fetched with scalar loads
+                const Node nu = load_node(S, i0);
+                run_prims<COUNT>(S, nu.kind, nu.first, nu.count, nu.chain, cur, s, e, best, tally);
+            } else {
+                run_prims<COUNT>(S, n.kind, n.first, n.count, n.chain, cur, s, e, best, tally);
             }
-            case RT_NODE_TRIANGLES: {
-                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
-                    double t;
-                    if (tri_t(S.tris + 16u * k, cur, s, e, t)) {
-                        best.t = t; best.ref = make_ref(RT_NODE_TRIANGLES, k); best.chain = n.chain;
-                        e = t;
-                    }
-                }
-                i = i + 1u;
-                break;
-            }
-            case RT_NODE_QUADRICS: {
-                for (uint32_t k = n.first; k < n.first + n.count; ++k) {
-                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
-                    double t;
-                    if (quadric_t(S.quadrics + 10u * k, cur, s, e, t)) {
-                        best.t = t; best.ref = make_ref(RT_NODE_QUADRICS, k); best.chain = n.chain;
-                        e = t;
-                    }
-                }
-                i = i + 1u;
-                break;
-            }
-            case RT_NODE_MEDIUM: {
-                if constexpr (MEDIA) {
-                    // ConstantMedium::hit, constant_medium.rs:46-93
-                    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
-                    const rt_medium m = S.media[n.first];
-                    double ray_length = sqrt(cur.a);  // of the ray the medium itself receives
-                    Best b1; b1.t = RT_INF; b1.ref = RT_NO_HIT; b1.chain = 0;
-                    lv_set(L, n.level + 1u, -RT_INF, RT_INF);
-                    walk<false, COUNT>(S, wray, i + 1u, n.skip, L, rng, b1, cur, cur_chain, tally);
-                    if (b1.ref != RT_NO_HIT) {
-                        Best b2; b2.t = RT_INF; b2.ref = RT_NO_HIT; b2.chain = 0;
-                        lv_set(L, n.level + 1u, b1.t + 0.0001, RT_INF);
-                        walk<false, COUNT>(S, wray, i + 1u, n.skip, L, rng, b2, cur, cur_chain, tally);
-                        if (b2.ref != RT_NO_HIT) {
-                            double t1 = fmax(b1.t, s);
-                            double t2 = fmin(b2.t, e);
-                            t1 = fmax(t1, 0.0);
-                            double inside = (t2 - t1) * ray_length;
-                            double x = rng_range(rng, 0.0, 1.0);
-                            double hit_distance = m.neg_inv_density * log(x);
-                            if (!(hit_distance > inside)) {
-                                best.t = t1 + hit_distance / ray_length;
-                                best.ref = make_ref(RT_NODE_MEDIUM, n.first);
-                                best.chain = n.chain;
-                            }
-                        }
-                    }
-                }
-                i = n.skip;
-                break;
-            }
-            default:
-                i = iend;  // unreachable for a validated scene
-                break;
+            i = i + 1u;
         }
     }
 }
 
 // world.hit(ray, tmin..tmax) (camera.rs:363): returns the closest hit as (t, ref, chain).
-template <bool COUNT>
-RT_HD Best closest_hit(const DScene& S, const Ray& wray, double tmin, double tmax, const Levels& L, Rng& rng,
+template <bool COUNT, bool LOCKSTEP, class Src>
+RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax, const Levels& L, RngPos& rng,
                        Tally& tally) {
     Best best; best.t = RT_INF; best.ref = RT_NO_HIT; best.chain = 0;
     lv_set(L, 0u, tmin, tmax);
-    Ray cur = wray;
+    Ray cur = src.world();
     uint32_t cur_chain = 0;
-    walk<true, COUNT>(S, wray, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
+    walk<true, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
     return best;
+}
+
+// The same walk as a per-lane state machine that does one BVH entry and one primitive test per step, for the
+// kernel that keeps every lane busy by handing it a new ray as soon as its ray is finished.
+#define RT_ST_NODE 0u
+#define RT_ST_RUN 1u
+#define RT_ST_DONE 2u
+struct Lane {
+    Ray cur;
+    uint32_t cur_chain;
+    uint32_t i;              // next entry of the flattened tree
+    uint32_t k, kend, kind;  // primitive run in progress (RT_ST_RUN)
+    double s, e;             // interval the run in progress is tested against
+    Best best;
+    uint32_t state;
+};
+template <class Src>
+RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const Levels& L) {
+    ln.cur = src.world();
+    ln.cur_chain = 0;
+    ln.i = 0;
+    ln.k = ln.kend = 0; ln.kind = 0;
+    ln.s = tmin; ln.e = tmax;
+    ln.best.t = RT_INF; ln.best.ref = RT_NO_HIT; ln.best.chain = 0;
+    ln.state = RT_ST_NODE;
+    lv_set(L, 0u, tmin, tmax);
+}
+// One entry of the tree for a lane in RT_ST_NODE.
+template <bool COUNT, class Src>
+RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Levels& L, RngPos& rng, Tally& tally) {
+    if (ln.i >= S.n_nodes) { ln.state = RT_ST_DONE; return; }
+    const Node n = load_node(S, ln.i);
+    if (n.chain != ln.cur_chain) { ln.cur = ray_in_chain(S, src.world(), n.chain); ln.cur_chain = n.chain; }
+    if (n.kind == RT_NODE_BVH) {
+        ln.i = bvh_step<COUNT>(S, n, ln.i, L, ln.best, ln.cur, tally);
+        return;
+    }
+    const double2 iv = lv_get(L, n.level);
+    const double s = iv.x, e = fmin(iv.y, ln.best.t);
+    if (n.kind == RT_NODE_MEDIUM) {
+        // ConstantMedium::hit, constant_medium.rs:46-93 (same steps as in walk())
+        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
+        const rt_medium m = S.media[n.first];
+        const double ray_length = sqrt(ln.cur.a);
+        double t1 = 0.0, t2 = 0.0, lo = -RT_INF;
+        bool ok = true;
+        for (int pass = 0; pass < 2 && ok; ++pass) {
+            Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
+            lv_set(L, n.level + 1u, lo, RT_INF);
+            walk<false, COUNT, false>(S, src, ln.i + 1u, n.skip, L, rng, b, ln.cur, ln.cur_chain, tally);
+            ok = b.ref != RT_NO_HIT;
+            if (pass == 0) t1 = b.t; else t2 = b.t;
+            lo = b.t + 0.0001;
+        }
+        if (ok) {
+            t1 = fmax(t1, s);
+            t2 = fmin(t2, e);
+            t1 = fmax(t1, 0.0);
+            double inside = (t2 - t1) * ray_length;
+            double x = rng_draw_at(rng.k0, rng.k1, rng.pixel, rng.sample, rng.ctr) * (1.0 - 0.0) + 0.0;
+            rng.ctr++;
+            double hit_distance = m.neg_inv_density * log(x);
+            if (!(hit_distance > inside)) {
+                ln.best.t = t1 + hit_distance / ray_length;
+                ln.best.ref = make_ref(RT_NODE_MEDIUM, n.first);
+                ln.best.chain = n.chain;
+            }
+        }
+        ln.i = n.skip;
+        return;
+    }
+    if (n.count == 0u) { ln.i = ln.i + 1u; return; }
+    ln.kind = n.kind; ln.k = n.first; ln.kend = n.first + n.count;
+    ln.s = s; ln.e = e;
+    ln.state = RT_ST_RUN;
+}
+// One primitive of the run in progress for a lane in RT_ST_RUN.
+template <bool COUNT>
+RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
+    double t;
+    bool hit;
+    if (ln.kind == RT_NODE_TRIANGLES || ln.kind == RT_NODE_QUADS) {
+        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+        const bool is_tri = ln.kind == RT_NODE_TRIANGLES;
+        const double2* rec = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads) + 8u * ln.k;
+        hit = planar_t(load_planar(rec), is_tri, ln.cur, ln.s, ln.e, t);
+    } else if (ln.kind == RT_NODE_SPHERES) {
+        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 40u; }
+        hit = sphere_t(reinterpret_cast<const double2*>(S.spheres) + 2u * ln.k, ln.cur, ln.s, ln.e, t);
+    } else {
+        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
+        hit = quadric_t(reinterpret_cast<const double2*>(S.quadrics) + 5u * ln.k, ln.cur, ln.s, ln.e, t);
+    }
+    if (hit) {
+        ln.best.t = t; ln.best.ref = make_ref(ln.kind, ln.k); ln.best.chain = ln.cur_chain;
+        ln.e = t;
+    }
+    ln.k = ln.k + 1u;
+    if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -437,8 +649,15 @@ RT_HD void sphere_uv(V3 p, double& u, double& v) {  // sphere.rs:90-98
 // Rebuilds the HitRecord of the closest hit exactly as the primitive's hit() fills it (sphere.rs:65-73,
 // parallelogram.rs:113-128, triangle.rs:137-152, quadric.rs:56-82, constant_medium.rs:79-90) in the ray space of
 // its chain, then maps p and normal back out through the instances (hittable/mod.rs:88,131-132).
-// WANT_UV = false skips the sphere's acos/atan2 when the caller knows the material ignores (u, v).
-template <bool WANT_UV>
+// FULL = false skips a sphere's acos/atan2 when its material cannot read (u, v): only an image texture does, and a
+// checker may lead to one.
+RT_HD bool mat_reads_uv(const DScene& S, uint32_t mat) {
+    const rt_material m = S.mats[mat];
+    if (m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC) return false;
+    const uint32_t k = S.texs[m.texture].kind;
+    return k == RT_TEX_IMAGE || k == RT_TEX_CHECKER;
+}
+template <bool FULL>
 RT_HD Rec finalize(const DScene& S, const Ray& wray, const Best& b) {
     Rec r;
     Ray ray = ray_in_chain(S, wray, b.chain);
@@ -450,8 +669,8 @@ RT_HD Rec finalize(const DScene& S, const Ray& wray, const Best& b) {
             const double* sp = S.spheres + 4u * k;
             V3 outward = (r.p - mk(sp[0], sp[1], sp[2])) / sp[3];
             face_normal(r, ray.d, outward);
-            if (WANT_UV) sphere_uv(outward, r.u, r.v);
             r.mat = S.sphere_mat[k]; r.prim_id = S.sphere_id[k];
+            if (FULL || mat_reads_uv(S, r.mat)) sphere_uv(outward, r.u, r.v);
             break;
         }
         case RT_NODE_QUADS:

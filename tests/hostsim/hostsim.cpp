@@ -29,6 +29,10 @@ static DScene to_dscene(const sim_scene* s) {
     return d;
 }
 
+static int mode = 0;  // 0 generic walk, 1 lockstep walk, 2 per-lane state machine
+extern "C" void sim_set_uniform_mode(int on) { host_uniform_mode() = on != 0; }
+extern "C" void sim_set_walk_mode(int m) { mode = m; }
+
 extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o3, const double* d3, const double* tmin,
                              const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim, double* t,
                              double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out, uint64_t* tallies2) {
@@ -38,9 +42,25 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
     uint64_t nt = 0, pt = 0;
     for (uint64_t i = 0; i < n; ++i) {
         Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
-        Rng rng = rng_make(seed, rng3 ? rng3[3 * i] : (uint32_t)i, rng3 ? rng3[3 * i + 1] : 0u, rng3 ? rng3[3 * i + 2] : 0u);
-        Ray w = ray_world(ld3(o3 + 3 * i), ld3(d3 + 3 * i));
-        Best b = closest_hit<true>(S, w, tmin[i], tmax[i], L, rng, tally);
+        RngPos rng;
+        rng.k0 = (uint32_t)seed; rng.k1 = (uint32_t)(seed >> 32);
+        rng.pixel = rng3 ? rng3[3 * i] : (uint32_t)i; rng.sample = rng3 ? rng3[3 * i + 1] : 0u; rng.ctr = rng3 ? rng3[3 * i + 2] : 0u;
+        RayAoS src; src.o3 = o3; src.d3 = d3; src.i = i;
+        Ray w = src.world();
+        Best b;
+        if (mode == 2) {  // the per-lane state machine of the persistent kernel
+            Lane ln;
+            lane_begin(ln, src, tmin[i], tmax[i], L);
+            while (ln.state != RT_ST_DONE) {
+                if (ln.state == RT_ST_NODE) lane_node_step<true>(S, src, ln, L, rng, tally);
+                if (ln.state == RT_ST_RUN) lane_prim_step<true>(S, ln, tally);
+            }
+            b = ln.best;
+        } else if (mode == 1) {
+            b = closest_hit<true, true>(S, src, tmin[i], tmax[i], L, rng, tally);
+        } else {
+            b = closest_hit<true, false>(S, src, tmin[i], tmax[i], L, rng, tally);
+        }
         nt += tally.node_tests; pt += tally.prim_tests;
         bool h = b.ref != RT_NO_HIT;
         Rec rec;
@@ -69,9 +89,12 @@ extern "C" int sim_trace_samples(const sim_scene* sc, const rt_camera* cam, uint
         V3 beta = mk(1.0, 1.0, 1.0), lum = mk(0, 0, 0);
         uint32_t rays = 0;
         for (uint32_t depth = 0; depth < max_depth; ++depth) {
-            Ray w = ray_world(o, d);
+            RayVal src; src.o = o; src.d = d;
+            Ray w = src.world();
             rays++;
-            Best b = closest_hit<false>(S, w, 0.001, RT_INF, L, rng, tally);
+            RngPos rp; rp.k0 = rng.k0; rp.k1 = rng.k1; rp.pixel = rng.pixel; rp.sample = rng.sample; rp.ctr = rng.ctr;
+            Best b = closest_hit<false, false>(S, src, 0.001, RT_INF, L, rp, tally);
+            rng.ctr = rp.ctr;
             if (b.ref == RT_NO_HIT) { lum = beta * mk(bg[0], bg[1], bg[2]); break; }
             Rec rec = finalize<true>(S, w, b);
             V3 nd, att, emit;

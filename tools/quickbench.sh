@@ -1,0 +1,13 @@
+#!/bin/bash
+# quick overview: reduced-spp runs of several configs (not valid metric lines; for development only)
+out=gpurun_out/quick_$1.log
+rm -f $out
+for c in C2:200 C3:100 C4:64 C5:32; do
+  timeout -k 10 300 python -u bench.py --config ${c%%:*} --spp ${c##*:} --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep metric | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); r=d['roofline']
+    print(d['config']['workload'][:22], 'Mrays/s %.0f'%d['value'], 'Mpaths/s %.0f'%d['mpaths_per_s'], 'ms/step %.1f'%d['ms_per_step'], 'trav_share %.2f'%r['traverse_share_of_step'], 'shade_ms %.1f'%r['shade_ms_per_step'], 'avg_launch_ms %.3f'%r['avg_launch_ms'], 'frac %.2f'%r['frac'])
+" >> $out || exit 1
+done
+cat $out
