@@ -80,11 +80,16 @@ def main():
     scene = spec.builder.commit(local_rank)
     film = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
 
-    def step(counters=False, nspp=spp):
-        st = scene.render_into(cam, nspp, spec.max_depth, spec.background, film.data_ptr(), spp_begin=rank * spp,
-                               batch_paths=args.batch_paths, counters=counters)
-        if dist is not None:
-            dist.all_reduce(film)  # sum of the per-GPU films over RCCL
+    from raytracer_amd.dist import render_sharded
+
+    def step():
+        st = {}
+
+        def render_range(begin, count):
+            st.update(scene.render_into(cam, count, spec.max_depth, spec.background, film.data_ptr(), spp_begin=begin,
+                                        batch_paths=args.batch_paths))
+
+        render_sharded(render_range, film, spp * world)  # rank r renders samples [r*spp, (r+1)*spp), then RCCL all-reduce
         return st
 
     def fence():

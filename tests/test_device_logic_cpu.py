@@ -1,0 +1,140 @@
+"""The per-lane device functions of raytracer_amd/csrc/rt_core.h (tree walk in its three forms, hit-record
+reconstruction, materials, textures, camera), compiled for the host by tests/hostsim and compared with the oracle
+bit for bit.  This is a logic check that runs without a GPU; the GPU tests repeat it on the real kernels."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import SMALL, HostSim, assert_hits_equal, build_pair, cameras, path_rays
+
+CONFIGS = ["C1", "C2", "C3", "C4", "C5"]
+
+
+@pytest.fixture(scope="module")
+def pairs():
+    cache = {}
+
+    def get(cfg):
+        if cfg not in cache:
+            hs, os_ = build_pair(cfg, **SMALL[cfg])
+            cache[cfg] = (hs, os_, HostSim(hs.builder))
+        return cache[cfg]
+
+    return get
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+@pytest.mark.parametrize("mode", ["generic-uniform", "generic-divergent", "lockstep", "lane-state-machine"])
+def test_walk_matches_oracle(pairs, cfg, mode):
+    hs, os_, sim = pairs(cfg)
+    if mode == "lockstep" and cfg in ("C1", "C4", "C5"):
+        pytest.skip("the lockstep walk is only used for trees without BVH entries")
+    L = helpers._sim_lib()
+    L.sim_set_walk_mode({"generic-uniform": 0, "generic-divergent": 0, "lockstep": 1, "lane-state-machine": 2}[mode])
+    L.sim_set_uniform_mode(0 if mode == "generic-divergent" else 1)
+    try:
+        _, oc = cameras(hs)
+        for bounce in (0, 2):
+            o, d, rng3 = path_rays(os_, oc, 1500, bounce)
+            want = os_.builder.intersect(o, d, 0.001, np.inf, rng3)
+            got = sim.intersect(o, d, 0.001, np.inf, rng3)
+            assert_hits_equal(got, want, exact=True, what=f"{cfg} {mode} bounce {bounce}")
+            assert got["counters"]["node_tests"] == want["counters"]["node_tests"]
+            assert got["counters"]["prim_tests"] == want["counters"]["prim_tests"]
+    finally:
+        L.sim_set_walk_mode(0)
+        L.sim_set_uniform_mode(1)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_arbitrary_intervals_and_directions(pairs, cfg):
+    """Rays that do not come from the camera: random origins inside the scene's extent, random directions, random
+    finite intervals (exercises negative t, rays starting inside boxes and spheres, axis-parallel directions)."""
+    hs, os_, sim = pairs(cfg)
+    rs = np.random.RandomState(17)
+    n = 2000
+    lo, hi = (-15.0, 15.0) if cfg == "C1" else (-50.0, 600.0)
+    o = rs.uniform(lo, hi, (n, 3))
+    d = rs.standard_normal((n, 3))
+    d[::7, 0] = 0.0   # axis-parallel components: 1/d = inf in the slab test
+    d[::11, 1] = 0.0
+    tmin = rs.uniform(-100.0, 10.0, n)
+    tmax = tmin + rs.uniform(0.0, 2000.0, n)
+    rng3 = np.stack([np.arange(n), np.full(n, 3), np.zeros(n)], axis=1).astype(np.uint32)
+    want = os_.builder.intersect(o, d, tmin, tmax, rng3)
+    got = sim.intersect(o, d, tmin, tmax, rng3)
+    assert_hits_equal(got, want, exact=True, what=cfg)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_per_sample_radiance(pairs, cfg):
+    hs, os_, sim = pairs(cfg)
+    hc, oc = cameras(hs)
+    rs = np.random.RandomState(2)
+    n = 600
+    pixel = rs.randint(0, hc.width * hc.height, n).astype(np.uint32)
+    sample = rs.randint(0, 50, n).astype(np.uint32)
+    want, want_rays = os_.builder.trace_samples(oc, pixel, sample, hs.max_depth, hs.background)
+    got, got_rays = sim.trace_samples(hc, pixel, sample, hs.max_depth, hs.background)
+    assert np.array_equal(got_rays, want_rays)
+    # same libm on both sides here, so only the order of the throughput product differs (a0*(a1*(..)) in the
+    # reference's recursion, ((a0*a1)*..) in the loop): a few ulp
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
+
+
+def test_random_scene_with_every_primitive_and_instance(pairs):
+    """A scene no benchmark has: all four primitive types in a BVH under nested Translate/RotateY, a medium whose
+    boundary is itself a BVH of boxes, checker-of-checker and perlin textures."""
+    from oracle import oracle as orc
+    from raytracer_amd import HostBuilder
+    from raytracer_amd.philox import SceneRng
+
+    def make(b):
+        rng = SceneRng(99)
+        tex = b.tex_checker(1.5, b.tex_checker(0.3, b.tex_solid(1, 0, 0), b.tex_solid(0, 1, 0)), b.tex_perlin(0.7, [rng.range(-1, 1) for _ in range(768)]))
+        mats = [b.mat_lambertian(tex), b.mat_metal(0.8, 0.7, 0.6, 0.3), b.mat_dielectric(1.4), b.mat_diffuse_light(b.tex_solid(4, 4, 4)), b.mat_isotropic(tex)]
+        lst = b.list_new()
+        for k in range(120):
+            c = rng.vector(-10.0, 10.0)
+            m = mats[k % 5]
+            which = k % 4
+            if which == 0:
+                b.list_add(lst, b.sphere(c, rng.range(0.3, 1.5), m))
+            elif which == 1:
+                b.list_add(lst, b.quad(c, rng.vector(-2, 2), rng.vector(-2, 2), m))
+            elif which == 2:
+                b.list_add(lst, b.triangle(c, rng.vector(-2, 2), rng.vector(-2, 2), m))
+            else:
+                b.list_add(lst, b.slice(b.box(c, (c[0] + 1.0, c[1] + 2.0, c[2] + 0.5), m)))
+        inst = b.translate(b.rotate_y(b.translate(b.bvh(lst), (1.0, -2.0, 0.5)), 33.0), (-3.0, 0.0, 4.0))
+        fog_boxes = b.list_new()
+        for k in range(20):
+            c = rng.vector(-8.0, 8.0)
+            b.list_add(fog_boxes, b.slice(b.box(c, (c[0] + 3.0, c[1] + 3.0, c[2] + 3.0), mats[0])))
+        fog = b.constant_medium(b.rotate_y(b.bvh(fog_boxes), -20.0), 0.3, b.tex_solid(0.9, 0.9, 0.9))
+        world = b.list_new()
+        b.list_add(world, inst)
+        b.list_add(world, b.y_cone((0.0, 6.0, 0.0), (3.0, 3.0, 3.0), mats[1]))
+        b.list_add(world, fog)
+        b.list_add(world, b.quadric_sphere((4.0, 1.0, -2.0), 2.0, mats[2]))
+        b.set_world(b.slice(world))
+
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    make(hb)
+    make(ob)
+    sim = HostSim(hb)
+    rs = np.random.RandomState(4)
+    n = 4000
+    o = rs.uniform(-25, 25, (n, 3))
+    d = -o + rs.uniform(-6, 6, (n, 3))
+    rng3 = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.uint32)
+    L = helpers._sim_lib()
+    for mode in (0, 2):
+        L.sim_set_walk_mode(mode)
+        try:
+            got = sim.intersect(o, d, 0.001, np.inf, rng3)
+        finally:
+            L.sim_set_walk_mode(0)
+        want = ob.intersect(o, d, 0.001, np.inf, rng3)
+        assert want["hit"].mean() > 0.3
+        assert_hits_equal(got, want, exact=True, what=f"random scene mode {mode}")

@@ -133,3 +133,65 @@ def test_counters_match_oracle(gpu_scenes):
     assert st["rays"] == ost["rays"]
     assert st["node_tests"] == ost["node_tests"]
     assert st["prim_tests"] == ost["prim_tests"]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_golden_ray_batches(gpu_scenes, cfg):
+    """The committed fixtures (tests/golden/oracle_rays_*.npz, made by tools/make_golden.py from the oracle)."""
+    import os
+    from helpers import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"oracle_rays_{cfg}.npz"))
+    hs, _, scene = gpu_scenes(cfg)
+    medium_ids = _medium_prim_ids(hs)
+    for bounce in (0, 1, 3):
+        r = scene.intersect(g[f"o{bounce}"], g[f"d{bounce}"], 0.001, np.inf, g[f"rng{bounce}"])
+        for k in ("hit", "prim", "front", "ctr"):
+            assert np.array_equal(r[k], g[f"{k}{bounce}"]), (cfg, bounce, k)
+        solid = ~np.isin(g[f"prim{bounce}"], medium_ids)
+        for k in ("t", "p", "n"):
+            assert np.array_equal(r[k][solid], g[f"{k}{bounce}"][solid]), (cfg, bounce, k)
+            np.testing.assert_allclose(r[k], g[f"{k}{bounce}"], rtol=1e-12, atol=1e-9)
+
+
+def test_render_agrees_with_reference_image():
+    """cornell_quadric at the settings of the reference's own render (600 px, 200 spp, depth 50; main.rs:851-852)
+    against the block means of images/cornell_box_two_cylinders_medium_quality.png kept in tests/golden."""
+    import os
+    from helpers import ROOT
+    from raytracer_amd import HostBuilder, camera_new, scenes
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "reference_cylinders_blockmeans.npz"))
+    spec = scenes.build("C3", HostBuilder(), width=600)
+    cam = camera_new(image_width=600, **spec.camera)
+    scene = spec.builder.commit(0)
+    film, _ = scene.render(cam, 200, 50, spec.background)
+    rgb = scene.tonemap(film, 200).astype(np.float64)
+    blocks = rgb.reshape(6, 100, 6, 100, 3).mean(axis=(1, 3))
+    diff = np.abs(blocks - ref["blocks"])
+    # both images are 200-spp estimates with independent noise; a 100x100 block averages 10^4 pixels
+    assert diff.max() < 3.0, diff.max()
+    assert diff.mean() < 1.0, diff.mean()
+    assert np.abs(rgb.mean(axis=(0, 1)) - ref["mean"]).max() < 0.75
+    assert abs((rgb == 255).mean() - float(ref["frac255"])) < 0.005
+    scene.close()
+
+
+def test_image_rmse_gpu_vs_oracle_at_equal_spp(gpu_scenes):
+    """Image check at equal spp and equal random streams.  The two renders trace the same paths except where a
+    last-bit difference between libm and the device library (log in the medium, sin in the perlin texture, pow in
+    Schlick) sends a path the other way; in final_scene, whose glass and fuzzy-metal spheres amplify such
+    differences, that happens to a fraction of a percent of the samples, each of which then contributes
+    independent noise.  Bounds: RMSE in 8-bit grey levels and the share of pixels off by more than one level."""
+    from oracle import oracle as orc
+    for cfg, rmse_max, off_max in (("C1", 0.5, 0.002), ("C5", 4.0, 0.03)):
+        hs, os_, scene = gpu_scenes(cfg)
+        hc, oc = cameras(hs)
+        spp = 16
+        film, _ = scene.render(hc, spp, hs.max_depth, hs.background)
+        want, _ = os_.builder.render(oc, spp, hs.max_depth, hs.background)
+        a = scene.tonemap(film, spp).astype(np.float64)
+        b = orc.tonemap(want, spp).astype(np.float64)
+        rmse = np.sqrt(np.mean((a - b) ** 2))
+        off = (np.abs(a - b).max(axis=2) > 1).mean()
+        assert rmse < rmse_max, (cfg, rmse)
+        assert off < off_max, (cfg, off)
+        assert 20 * np.log10(255.0 / max(rmse, 1e-9)) > 36.0  # PSNR

@@ -1,9 +1,9 @@
 import sys; sys.path.insert(0,'.')
 from raytracer_amd import HostBuilder, camera_new, scenes
-import numpy as np
 cfg, spp = sys.argv[1], int(sys.argv[2])
+counters = len(sys.argv) > 3 and sys.argv[3] == "count"
 spec = scenes.build(cfg, HostBuilder())
 cam = camera_new(image_width=spec.width, **spec.camera)
 sc = spec.builder.commit(0)
-film, st = sc.render(cam, spp, spec.max_depth, spec.background, batch_paths=1<<27)
-print(cfg, st)
+film, st = sc.render(cam, spp, spec.max_depth, spec.background, counters=counters)
+print(cfg, {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}, "Mrays/s %.0f" % (st["rays"] / st["ms_total"] / 1e3))
