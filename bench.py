@@ -119,9 +119,16 @@ def main():
 
     if rank == 0:
         # per-ray algorithmic work of this workload, from the device counters (one untimed pass at reduced spp)
-        cst = scene.render_into(cam, min(spp, 4), spec.max_depth, spec.background, film.data_ptr(), counters=True)
+        # with the cull boxes off, i.e. the box and primitive tests the reference's algorithm performs; the timed
+        # steps skip part of that work (cull boxes), which is reported beside it
+        cst = scene.render_into(cam, min(spp, 4), spec.max_depth, spec.background, film.data_ptr(), counters=True,
+                                cull=False)
         n_node = cst["node_tests"] / cst["rays"]
         prim_bytes = cst["prim_bytes"] / cst["rays"]
+        dst = scene.render_into(cam, min(spp, 4), spec.max_depth, spec.background, film.data_ptr(), counters=True)
+        done = {"node_visits_per_ray": dst["node_tests"] / dst["rays"], "cull_tests_per_ray": dst["cull_tests"] / dst["rays"],
+                "prim_tests_per_ray": dst["prim_tests"] / dst["rays"], "prim_bytes_per_ray": dst["prim_bytes"] / dst["rays"],
+                "reference_prim_tests_per_ray": cst["prim_tests"] / cst["rays"]}
         b_trav = S_NODE * n_node + prim_bytes + S_STATE + S_HIT        # traverse+intersect launch
         b_ray = S_NODE * n_node + prim_bytes + 2 * S_STATE + 2 * S_HIT  # whole bounce
         launches = sum(s["traverse_launches"] for s in stats)
@@ -147,7 +154,8 @@ def main():
                          "bytes_per_ray_traverse": b_trav, "bytes_per_ray_bounce": b_ray, "node_tests_per_ray": n_node,
                          "prim_bytes_per_ray": prim_bytes, "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "traverse_share_of_step": ms_trav / (elapsed * 1e3),
-                         "shade_ms_per_step": sum(s["ms_shade"] for s in stats) / args.steps},
+                         "shade_ms_per_step": sum(s["ms_shade"] for s in stats) / args.steps,
+                         "work_done_with_cull_boxes": done},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(key, width)

@@ -93,6 +93,9 @@ typedef struct rt_medium {
  *   MEDIUM  one ConstantMedium: `first` indexes the medium table; its boundary subtree follows and ends at
  *           `skip`.  A boundary subtree must not contain another medium.
  *   run     `count` consecutive primitives of one type starting at `first` in that type's array, in list order.
+ *   CULL    no counterpart in the reference: `first` indexes a box that conservatively bounds every point the
+ *           entries up to `skip` can report a hit at.  A ray whose interval misses it skips them; nothing is
+ *           narrowed, so results are unchanged.  It does not count as a level.
  * Slices and instances leave no entry: a slice is just its children in sequence, an instance is a change of
  * `chain`.  `level` is the number of enclosing BVH/MEDIUM entries: an entry reads the ray interval of level
  * `level` and a BVH/MEDIUM entry writes the narrowed interval of level `level + 1` (bvh.rs:31-37).
@@ -103,7 +106,8 @@ enum rt_node_kind {
     RT_NODE_SPHERES = 2,
     RT_NODE_QUADS = 3,
     RT_NODE_TRIANGLES = 4,
-    RT_NODE_QUADRICS = 5
+    RT_NODE_QUADRICS = 5,
+    RT_NODE_CULL = 6
 };
 typedef struct rt_node {
     uint8_t kind;
@@ -134,12 +138,14 @@ typedef struct rt_render_opts {
     uint64_t batch_paths; /* paths in flight per wavefront batch; 0 = library default */
 } rt_render_opts;
 #define RT_FLAG_COUNTERS 1u /* also count BVH box tests and primitive tests (slower) */
+#define RT_FLAG_NO_CULL 2u  /* ignore the conservative cull boxes: do exactly the tests the reference does */
 
 typedef struct rt_stats {
     uint64_t paths;      /* camera samples traced */
     uint64_t rays;       /* world.hit calls: one per bounce including the camera ray (camera.rs:363,429) */
     uint64_t node_tests; /* AABB::hit calls, only with RT_FLAG_COUNTERS */
     uint64_t prim_tests; /* primitive / medium hit calls, only with RT_FLAG_COUNTERS */
+    uint64_t cull_tests; /* conservative cull-box tests (not in the reference), only with RT_FLAG_COUNTERS */
     uint64_t prim_bytes; /* bytes of the primitive records those calls read (sphere 40, quad/triangle 136, quadric 88,
                             medium 16), only with RT_FLAG_COUNTERS */
     double ms_total;     /* device time of the whole call */
@@ -182,6 +188,12 @@ int rt_scene_set_xforms(rt_scene* s, const rt_xform_op* ops, uint32_t n_ops, con
 /* The flattened BVHNode / HittableSlice tree (bvh.rs:13-26, hittable_list.rs:72-75) and the BVHNode boxes
  * (aabb.rs:8-12), 6 f64 per box: x.start, x.end, y.start, y.end, z.start, z.end. */
 int rt_scene_set_nodes(rt_scene* s, const rt_node* nodes, uint32_t n_nodes, const double* boxes6, uint32_t n_boxes);
+/* Optional, no counterpart in the reference: for box k of rt_scene_set_nodes that belongs to a BVH entry, a box
+ * (same 6-f64 layout, +-inf allowed) that conservatively bounds every point the entry's subtree can report a hit
+ * at, in the entry's own ray space.  The reference's own boxes are inflated towards the origin (aabb.rs:29-33 seeds
+ * every union with the point 1e-4) and must be kept for their narrowing; these let a ray skip a subtree it cannot
+ * hit before that narrowing is done.  Call after rt_scene_set_nodes; n_boxes must match. */
+int rt_scene_set_cull_boxes(rt_scene* s, const double* tight6, uint32_t n_boxes);
 /* Validates the description and uploads it to HIP device `device`. */
 int rt_scene_commit(rt_scene* s, int device);
 

@@ -58,7 +58,8 @@ uint32_t rth_num_prim_ids(rth_builder* b);
  *       6 media(rt_medium) 7 ops(rt_xform_op) 8 chains(rt_chain) 9 materials(rt_material) 10 textures(rt_texture)
  *       11 sphere_id 12 quad_id 13 tri_id 14 quadric_id (u32) 15 sphere_mat 16 quad_mat 17 tri_mat 18 quadric_mat
  *       19 image texels (RGB8 pixels, images back to back) 20 image descriptors (first pixel, w, h: 3 u32)
- *       21 perlin vectors (768 f64 per table) 22 perlin permutations (768 u32 per table) */
+ *       21 perlin vectors (768 f64 per table) 22 perlin permutations (768 u32 per table)
+ *       23 cull boxes (6 f64, one per entry of 1) */
 const void* rth_flat_array(rth_builder* b, int what, uint64_t* count);
 /* FlatScene::commit: returns a committed rt_scene (caller destroys it with rt_scene_destroy) or NULL */
 rt_scene* rth_commit(rth_builder* b, int device);

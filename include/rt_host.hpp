@@ -135,6 +135,7 @@ struct FlatScene {
     struct Perlin { std::vector<double> vec; std::vector<uint32_t> perm; };
     std::vector<Perlin> perlins;
     std::vector<double> spheres, quads, triangles, quadrics, boxes;
+    std::vector<double> cull_boxes;  // one per entry of `boxes`: conservative bounds of the subtree's hit points
     std::vector<uint32_t> sphere_mat, sphere_id, quad_mat, quad_id, tri_mat, tri_id, quadric_mat, quadric_id;
     std::vector<rt_medium> media;
     std::vector<rt_xform_op> ops;
@@ -153,6 +154,10 @@ public:
     virtual ~Hittable() {}
     const AABB& bounding_box() const { return bbox_; }
     virtual void flatten(Flattener& f) const = 0;
+    // Geometric bounds, in the frame the object's parent sees, of every point a hit on this object can be reported
+    // at: grows [lo, hi] (which start out empty).  Unlike bounding_box() this is not part of the reference; it only
+    // feeds the cull boxes, which skip work without changing results.  Unbounded objects set +-infinity.
+    virtual void extent(double lo[3], double hi[3]) const = 0;
 protected:
     AABB bbox_;
 };
@@ -165,6 +170,7 @@ public:
     MaterialPtr material;
     Sphere(Point3 center, double radius, MaterialPtr material);
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 class Parallelogram : public Hittable {  // parallelogram.rs:12-58
 public:
@@ -173,6 +179,7 @@ public:
     MaterialPtr material;
     Parallelogram(Point3 q, Vector3 u, Vector3 v, MaterialPtr material);
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 class Triangle : public Hittable {  // triangle.rs:11-87
 public:
@@ -182,6 +189,7 @@ public:
     Triangle(Point3 q, Vector3 u, Vector3 v, MaterialPtr material);
     static std::shared_ptr<Triangle> from_vertex_locations(Point3 v1, Point3 v2, Point3 v3, MaterialPtr material);
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 class Quadric : public Hittable {  // quadric.rs:14-21
 public:
@@ -189,6 +197,7 @@ public:
     double j;
     MaterialPtr material;
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
     friend std::shared_ptr<Quadric> make_quadric(Point3, Point3, Point3, double, MaterialPtr, AABB);
 };
 std::shared_ptr<Quadric> y_cylinder(Point3 center, double radius, MaterialPtr material);      // quadric.rs:110-135
@@ -213,7 +222,9 @@ class HittableSlice : public Hittable {  // hittable_list.rs:72-106
 public:
     std::vector<HittablePtr> objects;
     static std::shared_ptr<HittableSlice> from_hittable_list(const HittableList& l);
+    void flatten_items(Flattener& f) const;  // the children in list order, nothing else
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 class BVHNode : public Hittable {  // bvh.rs:13-139
 public:
@@ -224,6 +235,7 @@ public:
     static std::shared_ptr<BVHNode> from_hittable_list(const HittableList& l);
     static std::shared_ptr<BVHNode> from_vec(std::vector<HittablePtr> objects);
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 class Translate : public Hittable {  // hittable/mod.rs:71-107
 public:
@@ -231,6 +243,7 @@ public:
     Vector3 offset;
     Translate(HittablePtr object, Vector3 offset);
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 class RotateY : public Hittable {  // hittable/mod.rs:110-189
 public:
@@ -238,6 +251,7 @@ public:
     double sin_theta, cos_theta;
     RotateY(HittablePtr object, double angle_in_degrees);
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 class ConstantMedium : public Hittable {  // constant_medium.rs:14-43
 public:
@@ -247,6 +261,7 @@ public:
     ConstantMedium(HittablePtr boundary, double density, TexturePtr texture);
     static std::shared_ptr<ConstantMedium> from_color(HittablePtr boundary, double density, Color color);
     void flatten(Flattener& f) const override;
+    void extent(double lo[3], double hi[3]) const override;
 };
 
 // load_model (load_obj.rs:15-115).  Throws std::runtime_error where the reference panics.

@@ -51,21 +51,22 @@ class rt_render_opts(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64),
-                ("prim_bytes", C.c_uint64),
+                ("cull_tests", C.c_uint64), ("prim_bytes", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_traverse", C.c_double), ("ms_shade", C.c_double),
                 ("traverse_launches", C.c_uint32), ("bounces", C.c_uint32)]
 
 
 RT_FLAG_COUNTERS = 1
+RT_FLAG_NO_CULL = 2
 RT_NO_HIT = 0xFFFFFFFF
-NODE_KINDS = {0: "bvh", 1: "medium", 2: "spheres", 3: "quads", 4: "triangles", 5: "quadrics"}
+NODE_KINDS = {0: "bvh", 1: "medium", 2: "spheres", 3: "quads", 4: "triangles", 5: "quadrics", 6: "cull"}
 
 # every symbol include/rt_amd.h declares
 RT_AMD_SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_last_error", "rt_scene_set_materials", "rt_scene_set_textures",
     "rt_scene_set_image", "rt_scene_set_perlin", "rt_scene_set_spheres", "rt_scene_set_quads",
     "rt_scene_set_triangles", "rt_scene_set_quadrics", "rt_scene_set_media", "rt_scene_set_xforms",
-    "rt_scene_set_nodes", "rt_scene_commit", "rt_intersect_batch", "rt_render", "rt_render_device",
+    "rt_scene_set_nodes", "rt_scene_set_cull_boxes", "rt_scene_commit", "rt_intersect_batch", "rt_render", "rt_render_device",
     "rt_trace_samples", "rt_tonemap_rgb8", "rt_debug_arith",
 ]
 
@@ -102,6 +103,7 @@ def amd():
     L.rt_scene_set_media.argtypes = [vp, vp, u32]
     L.rt_scene_set_xforms.argtypes = [vp, vp, u32, vp, u32]
     L.rt_scene_set_nodes.argtypes = [vp, vp, u32, vp, u32]
+    L.rt_scene_set_cull_boxes.argtypes = [vp, vp, u32]
     L.rt_scene_commit.argtypes = [vp, i32]
     L.rt_intersect_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), vp, C.POINTER(rt_stats)]

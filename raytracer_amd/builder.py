@@ -135,7 +135,8 @@ class HostBuilder:
              "quadrics": (5, 10), "media": (6, _lib.rt_medium), "ops": (7, _lib.rt_xform_op),
              "chains": (8, _lib.rt_chain), "materials": (9, _lib.rt_material), "textures": (10, _lib.rt_texture),
              "sphere_id": (11, "u32"), "quad_id": (12, "u32"), "tri_id": (13, "u32"), "quadric_id": (14, "u32"),
-             "sphere_mat": (15, "u32"), "quad_mat": (16, "u32"), "tri_mat": (17, "u32"), "quadric_mat": (18, "u32")}
+             "sphere_mat": (15, "u32"), "quad_mat": (16, "u32"), "tri_mat": (17, "u32"), "quadric_mat": (18, "u32"),
+             "cull_boxes": (23, 6)}
 
     def flat_ptr(self, what):
         """(address, count) of flattened array number `what` (see include/rt_host.h), owned by the builder."""

@@ -382,6 +382,8 @@ public:
     std::map<std::vector<std::pair<uint32_t, std::vector<double>>>, uint32_t> chain_ids;
     uint32_t level = 0;
     bool in_medium = false;
+    uint32_t slice_depth = 0;   // HittableSlice nesting of the object being flattened
+    size_t merge_barrier = 0;   // runs below this index are closed: a new primitive must not extend them
 
     Flattener() {
         rt_chain c0 = {0, 0};
@@ -481,7 +483,7 @@ public:
     }
     void emit_run(rt_node_kind kind, uint32_t index) {
         uint32_t ch = chain();
-        if (!out.nodes.empty()) {
+        if (out.nodes.size() > merge_barrier) {
             rt_node& last = out.nodes.back();
             if (last.kind == kind && last.level == level && last.chain == ch && last.first + last.count == index) {
                 last.count++;
@@ -514,7 +516,113 @@ public:
         level--;
         out.nodes[at].skip = (uint32_t)out.nodes.size();
     }
+    // A CULL entry brackets the entries up to close_cull() without opening an interval level.
+    size_t open_cull(uint32_t box) {
+        rt_node n;
+        n.kind = (uint8_t)RT_NODE_CULL;
+        n.level = (uint8_t)level;
+        n.chain = (uint16_t)chain();
+        n.first = box;
+        n.count = 0;
+        n.skip = 0;
+        out.nodes.push_back(n);
+        return out.nodes.size() - 1;
+    }
+    void close_cull(size_t at) {
+        out.nodes[at].skip = (uint32_t)out.nodes.size();
+        merge_barrier = out.nodes.size();
+    }
+    // Appends a box and its cull box; returns the box index.
+    uint32_t add_box(const double ref[6], const double cull[6]) {
+        uint32_t k = (uint32_t)(out.boxes.size() / 6);
+        out.boxes.insert(out.boxes.end(), ref, ref + 6);
+        out.cull_boxes.insert(out.cull_boxes.end(), cull, cull + 6);
+        return k;
+    }
 };
+
+// ---- extents and cull boxes ----------------------------------------------------------------------------------
+static void extent_empty(double lo[3], double hi[3]) {
+    for (int c = 0; c < 3; ++c) { lo[c] = INF; hi[c] = -INF; }
+}
+static void extent_add(double lo[3], double hi[3], Point3 p) {
+    const double v[3] = {p.x, p.y, p.z};
+    for (int c = 0; c < 3; ++c) { lo[c] = std::fmin(lo[c], v[c]); hi[c] = std::fmax(hi[c], v[c]); }
+}
+static void extent_everything(double lo[3], double hi[3]) {
+    for (int c = 0; c < 3; ++c) { lo[c] = -INF; hi[c] = INF; }
+}
+// The extent of `h` widened by a margin that dwarfs the rounding of the intersection routines and of the box test
+// itself (their errors are of the order 1e-16 relative to the coordinates involved), as x0 x1 y0 y1 z0 z1.
+// Returns false when the extent is unbounded or empty: such a box never culls.
+static bool cull_box_of(const Hittable& h, double out[6]) {
+    double lo[3], hi[3];
+    extent_empty(lo, hi);
+    h.extent(lo, hi);
+    bool bounded = true;
+    double big = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        if (!(lo[c] <= hi[c]) || std::isinf(lo[c]) || std::isinf(hi[c])) bounded = false;
+        big = std::fmax(big, std::fmax(std::fabs(lo[c]), std::fabs(hi[c])));
+    }
+    if (!bounded) {
+        for (int c = 0; c < 3; ++c) { out[2 * c] = -INF; out[2 * c + 1] = INF; }
+        return false;
+    }
+    const double margin = 1e-5 * (1.0 + big);
+    for (int c = 0; c < 3; ++c) { out[2 * c] = lo[c] - margin; out[2 * c + 1] = hi[c] + margin; }
+    return true;
+}
+void Sphere::extent(double lo[3], double hi[3]) const {
+    Point3 rv(radius, radius, radius);
+    extent_add(lo, hi, center - rv);
+    extent_add(lo, hi, center + rv);
+}
+void Parallelogram::extent(double lo[3], double hi[3]) const {
+    extent_add(lo, hi, q); extent_add(lo, hi, q + u); extent_add(lo, hi, q + v); extent_add(lo, hi, q + u + v);
+}
+void Triangle::extent(double lo[3], double hi[3]) const {
+    extent_add(lo, hi, q); extent_add(lo, hi, q + u); extent_add(lo, hi, q + v);
+}
+void Quadric::extent(double lo[3], double hi[3]) const { extent_everything(lo, hi); }  // the surfaces are unbounded
+void HittableSlice::extent(double lo[3], double hi[3]) const {
+    for (auto& o : objects) o->extent(lo, hi);
+}
+void BVHNode::extent(double lo[3], double hi[3]) const {
+    if (leaf) { objects->extent(lo, hi); return; }
+    left->extent(lo, hi);
+    right->extent(lo, hi);
+}
+void Translate::extent(double lo[3], double hi[3]) const {
+    double a[3], b[3];
+    extent_empty(a, b);
+    object->extent(a, b);
+    if (!(a[0] <= b[0])) return;  // empty
+    extent_add(lo, hi, Point3(a[0] + offset.x, a[1] + offset.y, a[2] + offset.z));
+    extent_add(lo, hi, Point3(b[0] + offset.x, b[1] + offset.y, b[2] + offset.z));
+}
+void RotateY::extent(double lo[3], double hi[3]) const {
+    double a[3], b[3];
+    extent_empty(a, b);
+    object->extent(a, b);
+    if (!(a[0] <= b[0])) return;  // empty
+    if (std::isinf(a[0]) || std::isinf(b[0]) || std::isinf(a[2]) || std::isinf(b[2])) {
+        extent_add(lo, hi, Point3(-INF, a[1], -INF));
+        extent_add(lo, hi, Point3(INF, b[1], INF));
+        return;
+    }
+    // object space -> parent space is the rotation hit points get (hittable/mod.rs:121-137): all 8 corners
+    for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 2; ++k) {
+            double x = i ? b[0] : a[0], z = k ? b[2] : a[2];
+            double px = cos_theta * x + sin_theta * z, pz = -sin_theta * x + cos_theta * z;
+            extent_add(lo, hi, Point3(px, a[1], pz));
+            extent_add(lo, hi, Point3(px, b[1], pz));
+        }
+}
+// A medium decides from the whole line, not from the ray's interval, whether it draws a random number
+// (constant_medium.rs:55-63), so nothing that contains one may be skipped on an interval test.
+void ConstantMedium::extent(double lo[3], double hi[3]) const { extent_everything(lo, hi); }
 
 void Sphere::flatten(Flattener& f) const {
     uint32_t k = (uint32_t)f.out.sphere_mat.size();
@@ -551,17 +659,31 @@ void Quadric::flatten(Flattener& f) const {
     f.out.quadric_id.push_back(f.prim_id(this));
     f.emit_run(RT_NODE_QUADRICS, k);
 }
-void HittableSlice::flatten(Flattener& f) const {
+void HittableSlice::flatten_items(Flattener& f) const {
+    f.slice_depth++;
     for (auto& o : objects) o->flatten(f);  // list order = visit order (hittable_list.rs:93-99)
+    f.slice_depth--;
+}
+void HittableSlice::flatten(Flattener& f) const {
+    // A list inside something else (a box of six sides, a group under an instance) gets a cull box of its own:
+    // the reference tests every child of a list against every ray that reaches the list.
+    double cull[6];
+    if (f.slice_depth > 0 && objects.size() >= 3 && cull_box_of(*this, cull)) {
+        size_t at = f.open_cull(f.add_box(cull, cull));
+        flatten_items(f);
+        f.close_cull(at);
+    } else {
+        flatten_items(f);
+    }
 }
 void BVHNode::flatten(Flattener& f) const {
-    uint32_t box = (uint32_t)(f.out.boxes.size() / 6);
     const AABB& b = bbox_;
     double rec[6] = {b.x.start, b.x.end, b.y.start, b.y.end, b.z.start, b.z.end};
-    f.out.boxes.insert(f.out.boxes.end(), rec, rec + 6);
-    size_t at = f.open(RT_NODE_BVH, box);
+    double cull[6];
+    cull_box_of(*this, cull);
+    size_t at = f.open(RT_NODE_BVH, f.add_box(rec, cull));
     if (leaf) {
-        objects->flatten(f);
+        objects->flatten_items(f);  // the leaf's own cull box already bounds them
     } else {
         left->flatten(f);  // bvh.rs:50-57: left first, then right
         right->flatten(f);
@@ -623,6 +745,7 @@ rt_scene* FlatScene::commit(int device) const {
     ok = ok && rt_scene_set_media(s, media.data(), (uint32_t)media.size()) == RT_OK;
     ok = ok && rt_scene_set_xforms(s, ops.data(), (uint32_t)ops.size(), chains.data(), (uint32_t)chains.size()) == RT_OK;
     ok = ok && rt_scene_set_nodes(s, nodes.data(), (uint32_t)nodes.size(), boxes.data(), (uint32_t)(boxes.size() / 6)) == RT_OK;
+    ok = ok && rt_scene_set_cull_boxes(s, cull_boxes.data(), (uint32_t)(cull_boxes.size() / 6)) == RT_OK;
     ok = ok && rt_scene_commit(s, device) == RT_OK;
     if (!ok) {
         rt_scene_destroy(s);

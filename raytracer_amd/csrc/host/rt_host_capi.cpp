@@ -182,6 +182,7 @@ const void* rth_flat_array(rth_builder* b, int what, uint64_t* count) {
         case 20: RET(b->image_desc, 3)
         case 21: RET(b->perlin_vec, 768)
         case 22: RET(b->perlin_perm, 768)
+        case 23: RET(f.cull_boxes, 6)
         default: return nullptr;
     }
 #undef RET

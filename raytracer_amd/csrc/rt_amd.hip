@@ -96,9 +96,13 @@ __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, 
     tmax = a.tmax ? a.tmax[idx] : RT_INF;
 }
 __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long long* tallies) {
-    unsigned long long a = tally.node_tests, b = tally.prim_tests, c = tally.prim_bytes;
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&tallies[0], a); atomicAdd(&tallies[1], b); atomicAdd(&tallies[2], c); }
+    unsigned long long a = tally.node_tests, b = tally.prim_tests, c = tally.prim_bytes, d = tally.cull_tests;
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); d += __shfl_down(d, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&tallies[0], a); atomicAdd(&tallies[1], b); atomicAdd(&tallies[2], c); atomicAdd(&tallies[3], d);
+    }
 }
 
 // world.hit(ray, 0.001..inf) for every queued path (camera.rs:363), for trees WITHOUT BVH entries: one lane per
@@ -107,7 +111,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
     if (idx < a.n) {
         RngPos rng;
         double tmin, tmax;
@@ -133,7 +137,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t pool_next = 0, pool_end = 0;
@@ -147,7 +151,6 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
     RngPos rng; rng.k0 = rng.k1 = rng.pixel = rng.sample = rng.ctr = 0;
     RaySoA src;
     src.ox = a.q.ox; src.oy = a.q.oy; src.oz = a.q.oz; src.dx = a.q.dx; src.dy = a.q.dy; src.dz = a.q.dz; src.idx = 0;
-    unsigned long long dbg[5] = {0, 0, 0, 0, 0};
     for (;;) {
         const bool need = ln.state == RT_ST_DONE;
         const unsigned long long mask = __ballot(need);
@@ -193,11 +196,9 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
         // Likewise a step runs only when enough lanes are waiting for it, or when it is what most lanes want.
         const bool do_node = n_node >= RT_STEP_THRESHOLD || n_node >= n_run;
         const bool do_run = n_run >= RT_STEP_THRESHOLD || n_run > n_node;
-        if (COUNT && lane == 0) { dbg[0]++; dbg[1] += do_node; dbg[2] += do_run; dbg[3] += do_node ? n_node : 0; dbg[4] += do_run ? n_run : 0; }
         if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT>(S, src, ln, L, rng, tally);
         if (do_run && ln.state == RT_ST_RUN) lane_prim_step<COUNT>(S, ln, tally);
     }
-    if (COUNT && lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&tallies[3 + k], dbg[k]);
     if (COUNT) tally_flush(tally, tallies);
 }
 
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_samples(DScene S, rt_camer
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
     Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
     V3 o, d;
     camera_ray(cam, pixel[i] % cam.width, pixel[i] / cam.width, rng, o, d);
@@ -368,7 +369,7 @@ struct rt_scene {
     std::vector<Image> images;
     struct Perlin { std::vector<double> vec; std::vector<uint32_t> perm; bool set = false; };
     std::vector<Perlin> perlins;
-    std::vector<double> spheres, quads, tris, quadrics, boxes;
+    std::vector<double> spheres, quads, tris, quadrics, boxes, cull_boxes;
     std::vector<uint32_t> sphere_mat, sphere_id, quad_mat, quad_id, tri_mat, tri_id, quadric_mat, quadric_id;
     std::vector<rt_medium> media;
     std::vector<rt_xform_op> ops;
@@ -382,6 +383,7 @@ struct rt_scene {
     uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
     std::vector<void*> allocs;
     DScene d;
+    const uint4* nodes_nocull = nullptr;  // the tree with every cull box infinite (RT_FLAG_NO_CULL)
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // render workspace, grown on demand
@@ -511,6 +513,12 @@ int rt_scene_set_nodes(rt_scene* s, const rt_node* nodes, uint32_t n_nodes, cons
     s->boxes.assign(boxes6, boxes6 + (size_t)6 * n_boxes);
     return RT_OK;
 }
+int rt_scene_set_cull_boxes(rt_scene* s, const double* tight6, uint32_t n_boxes) {
+    NEED_UNCOMMITTED(s);
+    if (n_boxes && !tight6) return fail(RT_ERR_INVALID, "null cull boxes");
+    s->cull_boxes.assign(tight6, tight6 + (size_t)6 * n_boxes);
+    return RT_OK;
+}
 
 // Everything the kernels index without checking is checked here.
 static int validate(rt_scene* s) {
@@ -560,19 +568,30 @@ static int validate(rt_scene* s) {
         if (s->ops[i].kind > RT_XF_ROTATE_Y) return fail(RT_ERR_INVALID, "transform op %zu: unknown kind", i);
 
     const uint32_t nn = (uint32_t)s->nodes.size(), nbox = (uint32_t)(s->boxes.size() / 6);
-    struct Open { uint32_t skip; bool medium; };
+    if (!s->cull_boxes.empty() && s->cull_boxes.size() != s->boxes.size())
+        return fail(RT_ERR_INVALID, "%zu cull boxes for %u boxes", s->cull_boxes.size() / 6, nbox);
+    for (size_t i = 0; i < s->cull_boxes.size(); ++i)
+        if (s->cull_boxes[i] != s->cull_boxes[i]) return fail(RT_ERR_INVALID, "cull box %zu: NaN bound", i / 6);
+    struct Open { uint32_t skip; bool medium; bool levelled; };
     std::vector<Open> open;
     uint32_t max_level = 0;
     for (uint32_t i = 0; i < nn; ++i) {
         while (!open.empty() && open.back().skip == i) open.pop_back();
         const rt_node& n = s->nodes[i];
-        if (n.level != open.size()) return fail(RT_ERR_INVALID, "node %u: level %u but %zu enclosing entries", i, n.level, open.size());
+        uint32_t depth = 0;
+        for (auto& o : open) depth += o.levelled;
+        if (n.level != depth) return fail(RT_ERR_INVALID, "node %u: level %u but %u enclosing BVH/medium entries", i, n.level, depth);
         if (n.chain >= s->chains.size()) return fail(RT_ERR_INVALID, "node %u: chain out of range", i);
         max_level = std::max<uint32_t>(max_level, n.level);
         uint32_t limit = open.empty() ? nn : open.back().skip;
         bool in_medium = false;
         for (auto& o : open) in_medium |= o.medium;
-        if (n.kind == RT_NODE_BVH || n.kind == RT_NODE_MEDIUM) {
+        if (n.kind == RT_NODE_CULL) {
+            if (n.skip <= i || n.skip > limit) return fail(RT_ERR_INVALID, "node %u: skip %u outside (%u, %u]", i, n.skip, i, limit);
+            if (n.first >= nbox) return fail(RT_ERR_INVALID, "node %u: box out of range", i);
+            Open o = {n.skip, false, false};
+            open.push_back(o);
+        } else if (n.kind == RT_NODE_BVH || n.kind == RT_NODE_MEDIUM) {
             if (n.skip <= i || n.skip > limit) return fail(RT_ERR_INVALID, "node %u: skip %u outside (%u, %u]", i, n.skip, i, limit);
             if (n.kind == RT_NODE_BVH) {
                 if (n.first >= nbox) return fail(RT_ERR_INVALID, "node %u: box out of range", i);
@@ -581,7 +600,7 @@ static int validate(rt_scene* s) {
                 if (in_medium) return fail(RT_ERR_LIMIT, "node %u: a medium inside a medium's boundary is not supported", i);
             }
             if (n.level + 2u > RT_MAX_LEVELS) return fail(RT_ERR_LIMIT, "node %u: nesting deeper than %d levels", i, RT_MAX_LEVELS);
-            Open o = {n.skip, n.kind == RT_NODE_MEDIUM};
+            Open o = {n.skip, n.kind == RT_NODE_MEDIUM, true};
             open.push_back(o);
             max_level = std::max<uint32_t>(max_level, n.level + 1u);
         } else {
@@ -597,7 +616,7 @@ static int validate(rt_scene* s) {
         }
     }
     while (!open.empty() && open.back().skip == nn) open.pop_back();
-    if (!open.empty()) return fail(RT_ERR_INVALID, "unterminated BVH/medium entry");
+    if (!open.empty()) return fail(RT_ERR_INVALID, "unterminated BVH/medium/cull entry");
     s->levels = max_level + 1u;
     s->has_bvh = false;
     for (uint32_t i = 0; i < nn; ++i) s->has_bvh |= s->nodes[i].kind == RT_NODE_BVH;
@@ -632,7 +651,36 @@ int rt_scene_commit(rt_scene* s, int device) {
     DScene& d = s->d;
     d.n_nodes = (uint32_t)s->nodes.size();
 #define UP(vec, field) if ((rc = upload(s, vec, &d.field))) return rc
-    UP(s->nodes, nodes); UP(s->boxes, boxes); UP(s->spheres, spheres); UP(s->quads, quads); UP(s->tris, tris);
+    // tree entries as the kernels read them, one 128-byte record each: header | box of a BVH or CULL entry | cull
+    // box of a BVH entry.  A second copy has every cull box infinite, so that nothing is culled.
+    {
+        const double everything[6] = {-RT_INF, RT_INF, -RT_INF, RT_INF, -RT_INF, RT_INF};
+        std::vector<uint4> rec((size_t)8 * s->nodes.size(), make_uint4(0, 0, 0, 0)), rec_nc;
+        for (size_t i = 0; i < s->nodes.size(); ++i) {
+            const rt_node& n = s->nodes[i];
+            std::memcpy(&rec[8 * i], &n, sizeof(rt_node));
+            if (n.kind == RT_NODE_BVH) {
+                std::memcpy(&rec[8 * i + 1], &s->boxes[(size_t)6 * n.first], 48);
+                std::memcpy(&rec[8 * i + 4], s->cull_boxes.empty() ? everything : &s->cull_boxes[(size_t)6 * n.first], 48);
+            } else if (n.kind == RT_NODE_CULL) {
+                std::memcpy(&rec[8 * i + 1], &s->boxes[(size_t)6 * n.first], 48);
+            }
+        }
+        rec_nc = rec;
+        for (size_t i = 0; i < s->nodes.size(); ++i) {
+            if (s->nodes[i].kind == RT_NODE_BVH) std::memcpy(&rec_nc[8 * i + 4], everything, 48);
+            else if (s->nodes[i].kind == RT_NODE_CULL) {
+                // a ray whose interval is already empty fails even an infinite box: make failing a no-op
+                rt_node n = s->nodes[i];
+                n.skip = (uint32_t)i + 1u;
+                std::memcpy(&rec_nc[8 * i], &n, sizeof(rt_node));
+                std::memcpy(&rec_nc[8 * i + 1], everything, 48);
+            }
+        }
+        UP(rec, nodes);
+        if ((rc = upload(s, rec_nc, &s->nodes_nocull))) return rc;
+    }
+    UP(s->spheres, spheres); UP(s->quads, quads); UP(s->tris, tris);
     UP(s->quadrics, quadrics); UP(s->sphere_mat, sphere_mat); UP(s->sphere_id, sphere_id); UP(s->quad_mat, quad_mat);
     UP(s->quad_id, quad_id); UP(s->tri_mat, tri_mat); UP(s->tri_id, tri_id); UP(s->quadric_mat, quadric_mat);
     UP(s->quadric_id, quadric_id); UP(s->media, media); UP(s->ops, ops); UP(s->chains, chains); UP(s->mats, mats);
@@ -704,17 +752,19 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 }  // extern "C++"
 
 // One traverse+intersect launch over the rays of `a` on the scene's stream.
-static int launch_traverse(rt_scene* s, const TravArgs& a, bool count) {
+static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocull = false) {
     const size_t lds = levels_lds(s, TRAV_BLOCK);
+    DScene d = s->d;
+    if (nocull) d.nodes = s->nodes_nocull;
     const uint32_t waves = (a.n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     if (!s->has_bvh) {
-        if (count) hipLaunchKernelGGL(k_traverse_lockstep<true>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_tallies);
-        else hipLaunchKernelGGL(k_traverse_lockstep<false>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_tallies);
+        if (count) hipLaunchKernelGGL(k_traverse_lockstep<true>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies);
+        else hipLaunchKernelGGL(k_traverse_lockstep<false>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies);
     } else {
         HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
         const uint32_t grid = std::min(waves, s->persist_waves);
-        if (count) hipLaunchKernelGGL(k_traverse_persistent<true>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_count + 4, s->d_tallies);
-        else hipLaunchKernelGGL(k_traverse_persistent<false>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, s->d, a, s->d_count + 4, s->d_tallies);
+        if (count) hipLaunchKernelGGL(k_traverse_persistent<true>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_count + 4, s->d_tallies);
+        else hipLaunchKernelGGL(k_traverse_persistent<false>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_count + 4, s->d_tallies);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -885,7 +935,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             TravArgs ta;
             std::memset(&ta, 0, sizeof ta);
             ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.n = n;
-            if ((rc = launch_traverse(s, ta, count))) return rc;
+            if ((rc = launch_traverse(s, ta, count, (o->flags & RT_FLAG_NO_CULL) != 0))) return rc;
             HIP_TRY(hipEventRecord(s->ev[2], sm));
             hipLaunchKernelGGL(k_shade, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, s->d, o->seed, n,
                                qin, s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0],
@@ -897,7 +947,6 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
             st.ms_traverse += ms;
-            if (getenv("RT_DEBUG_BOUNCES")) fprintf(stderr, "iter %u n %u traverse_ms %.3f Mrays/s %.0f\n", iter, n, ms, n / ms / 1e3);
             HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
             st.ms_shade += ms;
             st.traverse_launches++;
@@ -923,12 +972,10 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     if (count) {
         unsigned long long h[8];
         HIP_TRY(hipMemcpy(h, s->d_tallies, 64, hipMemcpyDeviceToHost));
-        if (getenv("RT_DEBUG"))
-            fprintf(stderr, "dbg rays %llu iters %llu node_steps %llu run_steps %llu node_lanes %llu run_lanes %llu node_tests %llu prim_tests %llu\n",
-                    (unsigned long long)st.rays, h[3], h[4], h[5], h[6], h[7], h[0], h[1]);
         st.node_tests = h[0];
         st.prim_tests = h[1];
         st.prim_bytes = h[2];
+        st.cull_tests = h[3];
     }
     if (stats) *stats = st;
     return RT_OK;

@@ -124,9 +124,9 @@ struct RngPos {  // what the walk needs of a path's random stream
 // starts 16-byte aligned and every record is a whole number of 16-byte pairs, so records are fetched as double2
 // (one 16-byte load per pair; a quad or triangle is exactly one 128-byte line).
 struct DScene {
-    const rt_node* nodes;
+    const uint4* nodes;      // 128 bytes (one cache line) per tree entry: rt_node header | box of a BVH or CULL entry
+                             // (3 x double2) | conservative cull box of a BVH entry (3 x double2) | 16 bytes unused
     uint32_t n_nodes;
-    const double* boxes;     // 6 per BVH entry
     const double* spheres;   // 4 per sphere: cx cy cz r
     const double* quads;     // 16 per quad: n(3) d q(3) u(3) v(3) w(3)
     const double* tris;      // 16 per triangle, same layout
@@ -150,7 +150,7 @@ struct Node {  // rt_node unpacked
     uint32_t kind, level, chain, skip, first, count;
 };
 RT_HD Node load_node(const DScene& S, uint32_t i) {
-    const uint4 raw = reinterpret_cast<const uint4*>(S.nodes)[i];
+    const uint4 raw = S.nodes[8u * i];
     Node n;
     n.kind = raw.x & 0xFFu; n.level = (raw.x >> 8) & 0xFFu; n.chain = raw.x >> 16;
     n.skip = raw.y; n.first = raw.z; n.count = raw.w;
@@ -231,13 +231,14 @@ struct Best {
     uint32_t chain;
 };
 struct Tally {
-    uint32_t node_tests, prim_tests, prim_bytes;
+    uint32_t node_tests, prim_tests, prim_bytes, cull_tests;
 };
 
 // True when every active lane of the wavefront holds the same x (returned in `first`).  Records addressed through
 // `first` are then fetched once per wavefront with scalar loads instead of once per lane.
 #if defined(__HIP_DEVICE_COMPILE__)
 RT_HD uint32_t wave_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+RT_HD bool wave_all(bool p) { return __all(p) != 0; }
 RT_HD bool wave_uniform(uint32_t x, uint32_t& first) {
     first = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
     return __all(x == first) != 0;
@@ -245,6 +246,7 @@ RT_HD bool wave_uniform(uint32_t x, uint32_t& first) {
 #else
 inline bool& host_uniform_mode() { static bool m = true; return m; }  // lets CPU tests take either branch
 RT_HD uint32_t wave_first(uint32_t x) { return x; }
+RT_HD bool wave_all(bool p) { return p && host_uniform_mode(); }  // "divergent" mode: some other lane always disagrees
 RT_HD bool wave_uniform(uint32_t x, uint32_t& first) { first = x; return host_uniform_mode(); }
 #endif
 
@@ -417,15 +419,26 @@ RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t co
     }
 }
 
+// Conservative cull test (no counterpart in the reference): false when the ray's interval (s, e) cannot touch the
+// box stored `at` 16-byte units into entry i's record, which bounds every point the entry's subtree can report a
+// hit at.  Nothing is narrowed; skipping a subtree that cannot produce a hit leaves the result unchanged.
+template <bool COUNT>
+RT_HD bool cull_pass(const DScene& S, uint32_t i, uint32_t at, Ray& cur, double s, double e, Tally& tally) {
+    if (COUNT) tally.cull_tests++;
+    ray_need_inv(cur);
+    return slab(reinterpret_cast<const double2*>(S.nodes + 8u * i + at), cur, s, e);
+}
+
 // BVHNode::hit's box test (bvh.rs:31-37) for the entry `n` at index i: returns the index to go on with.
 template <bool COUNT>
 RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels& L, const Best& best, Ray& cur,
                         Tally& tally) {
-    if (COUNT) tally.node_tests++;
     ray_need_inv(cur);
     double2 iv = lv_get(L, n.level);
     double s = iv.x, e = fmin(iv.y, best.t);
-    if (slab(reinterpret_cast<const double2*>(S.boxes) + 3u * n.first, cur, s, e)) {
+    if (COUNT) tally.node_tests++;
+    if (!cull_pass<COUNT>(S, i, 4u, cur, s, e, tally)) return n.skip;
+    if (slab(reinterpret_cast<const double2*>(S.nodes + 8u * i + 1u), cur, s, e)) {
         lv_set(L, n.level + 1u, s, e);
         return i + 1u;
     }
@@ -444,9 +457,12 @@ RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels
 //
 // LOCKSTEP = true is for trees without BVH entries: every lane then visits the same entries in the same order, so
 // the per-lane branches are dropped and all scene data comes through scalar loads.
+//
+// `mute` (LOCKSTEP only): a lane whose ray fails a CULL entry's box cannot leave the common sequence, so it sits out
+// every entry below `mute` instead.
 template <bool MEDIA, bool COUNT, bool LOCKSTEP, class Src>
 RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, const Levels& L, RngPos& rng, Best& best,
-                Ray& cur, uint32_t& cur_chain, Tally& tally) {
+                Ray& cur, uint32_t& cur_chain, uint32_t& mute, Tally& tally) {
     for (;;) {
         Node n;
         n.kind = RT_NODE_BVH; n.level = 0; n.chain = 0; n.skip = 0; n.first = 0; n.count = 0;
@@ -470,8 +486,16 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
         if (n.chain != cur_chain) { cur = ray_in_chain(S, src.world(), n.chain); cur_chain = n.chain; }
         const double2 iv = lv_get(L, n.level);
         const double s = iv.x, e = fmin(iv.y, best.t);
-        if (n.kind == RT_NODE_MEDIUM) {
-            if constexpr (MEDIA) {
+        const bool active = !LOCKSTEP || i >= mute;
+        if (n.kind == RT_NODE_CULL) {
+            if (LOCKSTEP) {
+                if (active && !cull_pass<COUNT>(S, wave_first(i), 1u, cur, s, e, tally)) mute = n.skip;
+                i = wave_all(mute >= n.skip) ? n.skip : i + 1u;
+            } else {
+                i = cull_pass<COUNT>(S, i, 1u, cur, s, e, tally) ? i + 1u : n.skip;
+            }
+        } else if (n.kind == RT_NODE_MEDIUM) {
+            if constexpr (MEDIA) if (active) {
                 // ConstantMedium::hit, constant_medium.rs:46-93
                 if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
                 const rt_medium m = S.media[n.first];
@@ -481,7 +505,7 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
                 for (int pass = 0; pass < 2 && ok; ++pass) {
                     Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
                     lv_set(L, n.level + 1u, lo, RT_INF);
-                    walk<false, COUNT, LOCKSTEP>(S, src, i + 1u, n.skip, L, rng, b, cur, cur_chain, tally);
+                    walk<false, COUNT, LOCKSTEP>(S, src, i + 1u, n.skip, L, rng, b, cur, cur_chain, mute, tally);
                     ok = b.ref != RT_NO_HIT;
                     if (pass == 0) t1 = b.t; else t2 = b.t;
                     lo = b.t + 0.0001;
@@ -509,7 +533,7 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
                 // all lanes stand on the same run (top-level lists, shared leaves): the entry and its records are
                 // addressed by a wavefront-uniform index and fetched with scalar loads
                 const Node nu = load_node(S, i0);
-                run_prims<COUNT>(S, nu.kind, nu.first, nu.count, nu.chain, cur, s, e, best, tally);
+                if (active) run_prims<COUNT>(S, nu.kind, nu.first, nu.count, nu.chain, cur, s, e, best, tally);
             } else {
                 run_prims<COUNT>(S, n.kind, n.first, n.count, n.chain, cur, s, e, best, tally);
             }
@@ -525,8 +549,8 @@ RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax
     Best best; best.t = RT_INF; best.ref = RT_NO_HIT; best.chain = 0;
     lv_set(L, 0u, tmin, tmax);
     Ray cur = src.world();
-    uint32_t cur_chain = 0;
-    walk<true, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
+    uint32_t cur_chain = 0, mute = 0;
+    walk<true, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, mute, tally);
     return best;
 }
 
@@ -562,11 +586,35 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
     const Node n = load_node(S, ln.i);
     if (n.chain != ln.cur_chain) { ln.cur = ray_in_chain(S, src.world(), n.chain); ln.cur_chain = n.chain; }
     if (n.kind == RT_NODE_BVH) {
-        ln.i = bvh_step<COUNT>(S, n, ln.i, L, ln.best, ln.cur, tally);
+        ray_need_inv(ln.cur);
+        const double2 bv = lv_get(L, n.level);
+        double bs = bv.x, be = fmin(bv.y, ln.best.t);
+        if (COUNT) tally.node_tests++;
+        if (!cull_pass<COUNT>(S, ln.i, 4u, ln.cur, bs, be, tally)) { ln.i = n.skip; return; }
+        if (!slab(reinterpret_cast<const double2*>(S.nodes + 8u * ln.i + 1u), ln.cur, bs, be)) { ln.i = n.skip; return; }
+        if (n.skip == ln.i + 2u) {
+            // a leaf whose children are one run of primitives (the usual case): go straight to the run with the
+            // narrowed interval in registers, without a round trip through the level slots
+            const Node r = load_node(S, ln.i + 1u);
+            if (r.kind >= RT_NODE_SPHERES && r.count > 0u && r.chain == n.chain) {
+                ln.kind = r.kind; ln.k = r.first; ln.kend = r.first + r.count;
+                ln.s = bs; ln.e = be;
+                ln.i = ln.i + 1u;
+                ln.state = RT_ST_RUN;
+                return;
+            }
+        }
+        lv_set(L, n.level + 1u, bs, be);
+        ln.i = ln.i + 1u;
         return;
     }
     const double2 iv = lv_get(L, n.level);
     const double s = iv.x, e = fmin(iv.y, ln.best.t);
+    if (n.kind == RT_NODE_CULL) {
+        ray_need_inv(ln.cur);
+        ln.i = cull_pass<COUNT>(S, ln.i, 1u, ln.cur, s, e, tally) ? ln.i + 1u : n.skip;
+        return;
+    }
     if (n.kind == RT_NODE_MEDIUM) {
         // ConstantMedium::hit, constant_medium.rs:46-93 (same steps as in walk())
         if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
@@ -577,7 +625,8 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         for (int pass = 0; pass < 2 && ok; ++pass) {
             Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
             lv_set(L, n.level + 1u, lo, RT_INF);
-            walk<false, COUNT, false>(S, src, ln.i + 1u, n.skip, L, rng, b, ln.cur, ln.cur_chain, tally);
+            uint32_t mute = 0;
+            walk<false, COUNT, false>(S, src, ln.i + 1u, n.skip, L, rng, b, ln.cur, ln.cur_chain, mute, tally);
             ok = b.ref != RT_NO_HIT;
             if (pass == 0) t1 = b.t; else t2 = b.t;
             lo = b.t + 0.0001;
@@ -604,28 +653,48 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
     ln.s = s; ln.e = e;
     ln.state = RT_ST_RUN;
 }
-// One primitive of the run in progress for a lane in RT_ST_RUN.
+// The next primitive(s) of the run in progress for a lane in RT_ST_RUN: two per step where the run has two left, so
+// that both records are in flight together and the step's fixed costs are shared.
 template <bool COUNT>
 RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
+    const bool two = ln.k + 1u < ln.kend;
     double t;
-    bool hit;
     if (ln.kind == RT_NODE_TRIANGLES || ln.kind == RT_NODE_QUADS) {
-        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
         const bool is_tri = ln.kind == RT_NODE_TRIANGLES;
         const double2* rec = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads) + 8u * ln.k;
-        hit = planar_t(load_planar(rec), is_tri, ln.cur, ln.s, ln.e, t);
+        const Planar g0 = load_planar(rec);
+        const Planar g1 = load_planar(rec + (two ? 8u : 0u));
+        if (COUNT) { tally.prim_tests += two ? 2u : 1u; tally.prim_bytes += two ? 272u : 136u; }
+        if (planar_t(g0, is_tri, ln.cur, ln.s, ln.e, t)) {
+            ln.best.t = t; ln.best.ref = make_ref(ln.kind, ln.k); ln.best.chain = ln.cur_chain;
+            ln.e = t;
+        }
+        if (two && planar_t(g1, is_tri, ln.cur, ln.s, ln.e, t)) {
+            ln.best.t = t; ln.best.ref = make_ref(ln.kind, ln.k + 1u); ln.best.chain = ln.cur_chain;
+            ln.e = t;
+        }
     } else if (ln.kind == RT_NODE_SPHERES) {
-        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 40u; }
-        hit = sphere_t(reinterpret_cast<const double2*>(S.spheres) + 2u * ln.k, ln.cur, ln.s, ln.e, t);
+        const double2* rec = reinterpret_cast<const double2*>(S.spheres) + 2u * ln.k;
+        if (COUNT) { tally.prim_tests += two ? 2u : 1u; tally.prim_bytes += two ? 80u : 40u; }
+        if (sphere_t(rec, ln.cur, ln.s, ln.e, t)) {
+            ln.best.t = t; ln.best.ref = make_ref(RT_NODE_SPHERES, ln.k); ln.best.chain = ln.cur_chain;
+            ln.e = t;
+        }
+        if (two && sphere_t(rec + 2u, ln.cur, ln.s, ln.e, t)) {
+            ln.best.t = t; ln.best.ref = make_ref(RT_NODE_SPHERES, ln.k + 1u); ln.best.chain = ln.cur_chain;
+            ln.e = t;
+        }
     } else {
         if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
-        hit = quadric_t(reinterpret_cast<const double2*>(S.quadrics) + 5u * ln.k, ln.cur, ln.s, ln.e, t);
+        if (quadric_t(reinterpret_cast<const double2*>(S.quadrics) + 5u * ln.k, ln.cur, ln.s, ln.e, t)) {
+            ln.best.t = t; ln.best.ref = make_ref(RT_NODE_QUADRICS, ln.k); ln.best.chain = ln.cur_chain;
+            ln.e = t;
+        }
+        ln.k = ln.k + 1u;
+        if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
+        return;
     }
-    if (hit) {
-        ln.best.t = t; ln.best.ref = make_ref(ln.kind, ln.k); ln.best.chain = ln.cur_chain;
-        ln.e = t;
-    }
-    ln.k = ln.k + 1u;
+    ln.k = ln.k + (two ? 2u : 1u);
     if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
 }
 

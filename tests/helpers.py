@@ -43,7 +43,7 @@ class sim_scene(C.Structure):
     _fields_ = [(n, C.c_void_p) if n != "n_nodes" else (n, C.c_uint64) for n in
                 ["nodes", "n_nodes", "boxes", "spheres", "quads", "tris", "quadrics", "sphere_mat", "sphere_id",
                  "quad_mat", "quad_id", "tri_mat", "tri_id", "quadric_mat", "quadric_id", "media", "ops", "chains",
-                 "mats", "texs", "texels", "image_desc", "perlin_vec", "perlin_perm"]]
+                 "mats", "texs", "texels", "image_desc", "perlin_vec", "perlin_perm", "cull_boxes"]]
 
 
 _SIM = None
@@ -68,7 +68,7 @@ class HostSim:
     ORDER = {"nodes": 0, "boxes": 1, "spheres": 2, "quads": 3, "tris": 4, "quadrics": 5, "media": 6, "ops": 7,
              "chains": 8, "mats": 9, "texs": 10, "sphere_id": 11, "quad_id": 12, "tri_id": 13, "quadric_id": 14,
              "sphere_mat": 15, "quad_mat": 16, "tri_mat": 17, "quadric_mat": 18, "texels": 19, "image_desc": 20,
-             "perlin_vec": 21, "perlin_perm": 22}
+             "perlin_vec": 21, "perlin_perm": 22, "cull_boxes": 23}
 
     def __init__(self, builder):
         self.builder = builder  # keeps the arrays alive
@@ -91,7 +91,7 @@ class HostSim:
         out = {"hit": np.zeros(n, np.uint8), "prim": np.zeros(n, np.uint32), "t": np.zeros(n), "p": np.zeros((n, 3)),
                "n": np.zeros((n, 3)), "uv": np.zeros((n, 2)), "front": np.zeros(n, np.uint8),
                "ctr": np.zeros(n, np.uint32)}
-        tl = (C.c_uint64 * 2)()
+        tl = (C.c_uint64 * 3)()
         vp = C.c_void_p
         self.L.sim_intersect(C.byref(self.sc), C.c_uint64(seed), vp(o.ctypes.data), vp(d.ctypes.data),
                              vp(tmin.ctypes.data), vp(tmax.ctypes.data),
@@ -99,8 +99,12 @@ class HostSim:
                              vp(out["hit"].ctypes.data), vp(out["prim"].ctypes.data), vp(out["t"].ctypes.data),
                              vp(out["p"].ctypes.data), vp(out["n"].ctypes.data), vp(out["uv"].ctypes.data),
                              vp(out["front"].ctypes.data), vp(out["ctr"].ctypes.data), tl)
-        out["counters"] = {"node_tests": tl[0], "prim_tests": tl[1]}
+        out["counters"] = {"node_tests": tl[0], "prim_tests": tl[1], "cull_tests": tl[2]}
         return out
+
+    def set_cull(self, on):
+        """on=False makes every cull box infinite (RT_FLAG_NO_CULL): the tests counted are then the reference's."""
+        self.L.sim_set_cull(1 if on else 0)
 
     def trace_samples(self, cam, pixel, sample, max_depth, background, seed=42):
         pixel = np.ascontiguousarray(pixel, dtype=np.uint32)

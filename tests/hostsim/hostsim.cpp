@@ -2,6 +2,7 @@
 // or path at a time, so that the flattened-tree walk can be compared with the oracle in a container without a GPU.
 // It is never linked into librt_amd.so or loaded by the raytracer_amd package.
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "../../raytracer_amd/csrc/rt_core.h"
@@ -16,11 +17,32 @@ struct sim_scene {  // host pointers to the arrays of a flattened scene
     const rt_medium* media; const rt_xform_op* ops; const rt_chain* chains; const rt_material* mats;
     const rt_texture* texs; const uint8_t* texels; const uint32_t* image_desc; const double* perlin_vec;
     const uint32_t* perlin_perm;
+    const double* cull_boxes;  // one per box, or null
 };
 
+static std::vector<uint4> g_records;
+static int use_cull = 1;  // 0: every cull box infinite, as under RT_FLAG_NO_CULL
 static DScene to_dscene(const sim_scene* s) {
     DScene d;
-    d.nodes = s->nodes; d.n_nodes = (uint32_t)s->n_nodes; d.boxes = s->boxes; d.spheres = s->spheres; d.quads = s->quads;
+    const double everything[6] = {-RT_INF, RT_INF, -RT_INF, RT_INF, -RT_INF, RT_INF};
+    const bool cull = use_cull && s->cull_boxes;
+    g_records.assign((size_t)8 * s->n_nodes, make_uint4(0, 0, 0, 0));
+    for (uint64_t i = 0; i < s->n_nodes; ++i) {
+        const rt_node& n = s->nodes[i];
+        std::memcpy(&g_records[8 * i], &n, sizeof(rt_node));
+        if (n.kind == RT_NODE_BVH) {
+            std::memcpy(&g_records[8 * i + 1], s->boxes + 6 * n.first, 48);
+            std::memcpy(&g_records[8 * i + 4], cull ? s->cull_boxes + 6 * n.first : everything, 48);
+        } else if (n.kind == RT_NODE_CULL) {
+            std::memcpy(&g_records[8 * i + 1], cull ? s->boxes + 6 * n.first : everything, 48);
+            if (!cull) {  // a ray whose interval is already empty fails even an infinite box: make failing a no-op
+                rt_node m = n;
+                m.skip = (uint32_t)i + 1u;
+                std::memcpy(&g_records[8 * i], &m, sizeof(rt_node));
+            }
+        }
+    }
+    d.nodes = g_records.data(); d.n_nodes = (uint32_t)s->n_nodes; d.spheres = s->spheres; d.quads = s->quads;
     d.tris = s->tris; d.quadrics = s->quadrics; d.sphere_mat = s->sphere_mat; d.sphere_id = s->sphere_id;
     d.quad_mat = s->quad_mat; d.quad_id = s->quad_id; d.tri_mat = s->tri_mat; d.tri_id = s->tri_id;
     d.quadric_mat = s->quadric_mat; d.quadric_id = s->quadric_id; d.media = s->media; d.ops = s->ops; d.chains = s->chains;
@@ -32,16 +54,17 @@ static DScene to_dscene(const sim_scene* s) {
 static int mode = 0;  // 0 generic walk, 1 lockstep walk, 2 per-lane state machine
 extern "C" void sim_set_uniform_mode(int on) { host_uniform_mode() = on != 0; }
 extern "C" void sim_set_walk_mode(int m) { mode = m; }
+extern "C" void sim_set_cull(int on) { use_cull = on; }
 
 extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o3, const double* d3, const double* tmin,
                              const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim, double* t,
-                             double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out, uint64_t* tallies2) {
+                             double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out, uint64_t* tallies3) {
     DScene S = to_dscene(sc);
     double2 slots[RT_MAX_LEVELS];
     Levels L; L.base = slots; L.stride = 1;
-    uint64_t nt = 0, pt = 0;
+    uint64_t nt = 0, pt = 0, ct = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
+        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
         RngPos rng;
         rng.k0 = (uint32_t)seed; rng.k1 = (uint32_t)(seed >> 32);
         rng.pixel = rng3 ? rng3[3 * i] : (uint32_t)i; rng.sample = rng3 ? rng3[3 * i + 1] : 0u; rng.ctr = rng3 ? rng3[3 * i + 2] : 0u;
@@ -61,7 +84,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
         } else {
             b = closest_hit<true, false>(S, src, tmin[i], tmax[i], L, rng, tally);
         }
-        nt += tally.node_tests; pt += tally.prim_tests;
+        nt += tally.node_tests; pt += tally.prim_tests; ct += tally.cull_tests;
         bool h = b.ref != RT_NO_HIT;
         Rec rec;
         rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
@@ -71,7 +94,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
         n3[3 * i] = rec.n.x; n3[3 * i + 1] = rec.n.y; n3[3 * i + 2] = rec.n.z;
         uv2[2 * i] = rec.u; uv2[2 * i + 1] = rec.v; front[i] = rec.front; ctr_out[i] = rng.ctr;
     }
-    tallies2[0] = nt; tallies2[1] = pt;
+    tallies3[0] = nt; tallies3[1] = pt; tallies3[2] = ct;
     return 0;
 }
 
@@ -82,7 +105,7 @@ extern "C" int sim_trace_samples(const sim_scene* sc, const rt_camera* cam, uint
     double2 slots[RT_MAX_LEVELS];
     Levels L; L.base = slots; L.stride = 1;
     for (uint64_t i = 0; i < n; ++i) {
-        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0;
+        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
         Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
         V3 o, d;
         camera_ray(*cam, pixel[i] % cam->width, pixel[i] / cam->width, rng, o, d);

@@ -24,14 +24,19 @@ def pairs():
 
 
 @pytest.mark.parametrize("cfg", CONFIGS)
-@pytest.mark.parametrize("mode", ["generic-uniform", "generic-divergent", "lockstep", "lane-state-machine"])
+@pytest.mark.parametrize("mode", ["generic-uniform", "generic-divergent", "lockstep", "lockstep-muted",
+                                  "lane-state-machine"])
 def test_walk_matches_oracle(pairs, cfg, mode):
+    """Every form of the walk returns the oracle's hits with the cull boxes in use; with the cull boxes switched
+    off it also performs exactly the oracle's box and primitive tests.  ("lockstep-muted": a lane that fails a cull
+    box stays in the common sequence and sits the subtree out, as when other lanes of its wavefront pass.)"""
     hs, os_, sim = pairs(cfg)
-    if mode == "lockstep" and cfg in ("C1", "C4", "C5"):
+    if mode.startswith("lockstep") and cfg in ("C1", "C4", "C5"):
         pytest.skip("the lockstep walk is only used for trees without BVH entries")
     L = helpers._sim_lib()
-    L.sim_set_walk_mode({"generic-uniform": 0, "generic-divergent": 0, "lockstep": 1, "lane-state-machine": 2}[mode])
-    L.sim_set_uniform_mode(0 if mode == "generic-divergent" else 1)
+    L.sim_set_walk_mode({"generic-uniform": 0, "generic-divergent": 0, "lockstep": 1, "lockstep-muted": 1,
+                         "lane-state-machine": 2}[mode])
+    L.sim_set_uniform_mode(0 if mode in ("generic-divergent", "lockstep-muted") else 1)
     try:
         _, oc = cameras(hs)
         for bounce in (0, 2):
@@ -39,11 +44,36 @@ def test_walk_matches_oracle(pairs, cfg, mode):
             want = os_.builder.intersect(o, d, 0.001, np.inf, rng3)
             got = sim.intersect(o, d, 0.001, np.inf, rng3)
             assert_hits_equal(got, want, exact=True, what=f"{cfg} {mode} bounce {bounce}")
+            assert got["counters"]["node_tests"] <= want["counters"]["node_tests"]
+            assert got["counters"]["prim_tests"] <= want["counters"]["prim_tests"]
+            sim.set_cull(False)
+            got = sim.intersect(o, d, 0.001, np.inf, rng3)
+            assert_hits_equal(got, want, exact=True, what=f"{cfg} {mode} bounce {bounce}, no culling")
             assert got["counters"]["node_tests"] == want["counters"]["node_tests"]
             assert got["counters"]["prim_tests"] == want["counters"]["prim_tests"]
+            sim.set_cull(True)
     finally:
+        sim.set_cull(True)
         L.sim_set_walk_mode(0)
         L.sim_set_uniform_mode(1)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_cull_boxes_save_work(pairs, cfg):
+    """What the cull boxes are for: fewer primitive tests on the benchmark scenes (and never more)."""
+    hs, os_, sim = pairs(cfg)
+    _, oc = cameras(hs)
+    o, d, rng3 = path_rays(os_, oc, 1500, 1)
+    sim.set_cull(False)
+    try:
+        base = sim.intersect(o, d, 0.001, np.inf, rng3)["counters"]
+    finally:
+        sim.set_cull(True)
+    with_cull = sim.intersect(o, d, 0.001, np.inf, rng3)["counters"]
+    print(cfg, "no cull", base, "cull", with_cull)
+    assert with_cull["prim_tests"] <= base["prim_tests"]
+    if cfg in ("C4", "C5"):
+        assert with_cull["prim_tests"] < 0.7 * base["prim_tests"]
 
 
 @pytest.mark.parametrize("cfg", CONFIGS)

@@ -128,11 +128,25 @@ def test_film_matches_oracle_render(gpu_scenes, cfg):
 def test_counters_match_oracle(gpu_scenes):
     hs, os_, scene = gpu_scenes("C4")
     hc, oc = cameras(hs)
-    film, st = scene.render(hc, 1, 1, hs.background, counters=True)  # camera rays only: no transcendental involved
-    _, ost = os_.builder.render(oc, 1, 1, hs.background)
+    # camera rays only: no transcendental involved.  With the cull boxes off the kernels do the reference's work
+    # test for test; with them on, the same film from less work.
+    film, st = scene.render(hc, 1, 1, hs.background, counters=True, cull=False)
+    ofilm, ost = os_.builder.render(oc, 1, 1, hs.background)
     assert st["rays"] == ost["rays"]
     assert st["node_tests"] == ost["node_tests"]
     assert st["prim_tests"] == ost["prim_tests"]
+    film_c, st_c = scene.render(hc, 1, 1, hs.background, counters=True)
+    assert np.array_equal(film_c, film) and np.array_equal(film, ofilm)
+    assert st_c["prim_tests"] < 0.7 * st["prim_tests"] and st_c["node_tests"] < st["node_tests"]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_cull_boxes_do_not_change_the_film(gpu_scenes, cfg):
+    hs, _, scene = gpu_scenes(cfg)
+    hc, _ = cameras(hs)
+    film, _ = scene.render(hc, 3, hs.max_depth, hs.background)
+    film_nc, _ = scene.render(hc, 3, hs.max_depth, hs.background, cull=False)
+    assert np.array_equal(film, film_nc)
 
 
 @pytest.mark.parametrize("cfg", CONFIGS)

@@ -36,17 +36,23 @@ def test_flattened_tree_is_well_formed(cfg):
     b = hs.builder
     nodes = b.flat("nodes")
     assert b.num_prims() == os_.builder.num_prims()
-    open_ = []
+    open_ = []  # (skip, opens an interval level) of the enclosing BVH / medium / cull entries
     counts = {k: 0 for k in _lib.NODE_KINDS.values()}
+    boxes, cull = b.flat("boxes"), b.flat("cull_boxes")
+    assert boxes.shape == cull.shape
     for i, n in enumerate(nodes):
-        while open_ and open_[-1] == i:
+        while open_ and open_[-1][0] == i:
             open_.pop()
-        assert n.level == len(open_)
+        assert n.level == sum(1 for _, lv in open_ if lv)
         kind = _lib.NODE_KINDS[n.kind]
-        if kind in ("bvh", "medium"):
-            assert i < n.skip <= (open_[-1] if open_ else len(nodes))
-            open_.append(n.skip)
+        if kind in ("bvh", "medium", "cull"):
+            assert i < n.skip <= (open_[-1][0] if open_ else len(nodes))
+            open_.append((n.skip, kind != "cull"))
             counts[kind] += 1
+            if kind != "medium":
+                assert n.first < len(boxes)
+                lo, hi = cull[n.first, 0::2], cull[n.first, 1::2]
+                assert (lo < hi).all()
         else:
             assert n.skip == i + 1 and n.count >= 1
             counts[kind] += n.count

@@ -1,9 +1,12 @@
 #!/bin/bash
 # quick overview: reduced-spp runs of several configs (not valid metric lines; for development only)
-out=gpurun_out/quick_$1.log
+# usage: tools/quickbench.sh <tag> [config:spp ...]
+tag=$1; shift
+cfgs=${@:-C2:200 C3:200 C4:200 C5:64 C1:10}
+out=gpurun_out/quick_$tag.log
 rm -f $out
-for c in C2:200 C3:100 C4:64 C5:32; do
-  timeout -k 10 300 python -u bench.py --config ${c%%:*} --spp ${c##*:} --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep metric | python -c "
+for c in $cfgs; do
+  timeout -k 10 400 python -u bench.py --config ${c%%:*} --spp ${c##*:} --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep metric | python -c "
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); r=d['roofline']
