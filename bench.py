@@ -131,16 +131,21 @@ def main():
                 "reference_prim_tests_per_ray": cst["prim_tests"] / cst["rays"]}
         b_trav = S_NODE * n_node + prim_bytes + S_STATE + S_HIT        # traverse+intersect launch
         b_ray = S_NODE * n_node + prim_bytes + 2 * S_STATE + 2 * S_HIT  # whole bounce
-        launches = sum(s["traverse_launches"] for s in stats)
-        ms_trav = sum(s["ms_traverse"] for s in stats)
         rays_local = sum(s["rays"] for s in stats)
+        fused = sum(s["path_launches"] for s in stats) > 0
+        if fused:  # whole paths in one kernel: the dominant kernel does the whole bounce
+            kernel, launches, ms_trav, b_kernel = "k_paths_lockstep", sum(s["path_launches"] for s in stats), \
+                sum(s["ms_paths"] for s in stats), b_ray
+        else:
+            kernel, launches, ms_trav, b_kernel = "k_traverse_persistent", sum(s["traverse_launches"] for s in stats), \
+                sum(s["ms_traverse"] for s in stats), b_trav
         avg_launch_ms = ms_trav / launches
-        achieved = (rays_local / launches) * b_trav / (avg_launch_ms * 1e-3) / 1e9
+        achieved = (rays_local / launches) * b_kernel / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             with open(tj) as fh:
-                traffic = json.load(fh).get(args.config, {}).get("k_traverse_hbm_bytes_per_launch")
+                traffic = json.load(fh).get(args.config, {}).get(kernel + "_hbm_bytes_per_launch")
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -149,9 +154,9 @@ def main():
             "config": {"workload": f"{args.config} {spec.name} {cam.width}x{cam.height}, {spp} spp per GPU, depth {spec.max_depth}",
                        "spp_total": spp * world, "paths_per_step": int(total_paths / args.steps), "seed": 42,
                        "parallelism": f"spp-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray_traverse": b_trav, "bytes_per_ray_bounce": b_ray, "node_tests_per_ray": n_node,
+                         "bytes_per_ray_kernel": b_kernel, "bytes_per_ray_traverse": b_trav, "bytes_per_ray_bounce": b_ray, "node_tests_per_ray": n_node,
                          "prim_bytes_per_ray": prim_bytes, "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "traverse_share_of_step": ms_trav / (elapsed * 1e3),
                          "shade_ms_per_step": sum(s["ms_shade"] for s in stats) / args.steps,

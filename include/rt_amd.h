@@ -139,6 +139,10 @@ typedef struct rt_render_opts {
 } rt_render_opts;
 #define RT_FLAG_COUNTERS 1u /* also count BVH box tests and primitive tests (slower) */
 #define RT_FLAG_NO_CULL 2u  /* ignore the conservative cull boxes: do exactly the tests the reference does */
+#define RT_FLAG_WHOLE_PATHS 4u /* scenes without BVH entries only (ignored otherwise): trace whole paths in one
+                                  kernel, path state in registers, instead of the queue-based schedule (one traverse
+                                  and one shade launch per bounce over all paths in flight); the film is the same
+                                  either way */
 
 typedef struct rt_stats {
     uint64_t paths;      /* camera samples traced */
@@ -151,8 +155,11 @@ typedef struct rt_stats {
     double ms_total;     /* device time of the whole call */
     double ms_traverse;  /* summed duration of the traverse+intersect launches (HIP events) */
     double ms_shade;     /* summed duration of the shade+compact launches */
+    double ms_paths;     /* summed duration of the whole-path launches (scenes without BVH entries) */
     uint32_t traverse_launches;
-    uint32_t bounces; /* deepest bounce any path reached */
+    uint32_t path_launches;
+    uint32_t bounces; /* most world.hit calls any one path made */
+    uint32_t reserved;
 } rt_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */

@@ -202,6 +202,106 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
     if (COUNT) tally_flush(tally, tallies);
 }
 
+// Whole paths for trees WITHOUT BVH entries, where every ray does the same work: get_ray, then ray_color as a
+// loop (camera.rs:349-408), one path per lane, and a lane takes the next path of the batch the moment its own ends
+// (paths are handed out in chunks of RT_CHUNK per wavefront, one atomic per chunk).  Path state never leaves the
+// registers: no queues, no hit buffer, no compaction.  The only traffic is one radiance per path into lum[] at the
+// path's batch index j = s_local * npix + pixel, which k_film_accumulate then adds up in sample order.
+// counters[0] += rays traced, counters[1] = max(deepest bounce).
+template <bool COUNT>
+__global__ void __launch_bounds__(TRAV_BLOCK, 2) k_paths_lockstep(DScene S, rt_camera cam, uint64_t seed, uint32_t npix,
+                                                                   uint32_t sample0, uint32_t npaths, uint32_t max_depth,
+                                                                   double bgr, double bgg, double bgb, double* lum_r,
+                                                                   double* lum_g, double* lum_b, uint32_t* work,
+                                                                   unsigned long long* counters,
+                                                                   unsigned long long* tallies) {
+    Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t pool_next = 0, pool_end = 0;
+    bool exhausted = false, alive = false;
+    V3 o = mk(0, 0, 0), d = mk(1, 1, 1), beta = mk(0, 0, 0);
+    uint32_t pix = 0, smp = 0, ctr = 0, depth = 0, slot = 0;
+    uint32_t rays = 0, deepest = 0;
+    for (;;) {
+        const unsigned long long mask = __ballot(!alive);
+        if (mask != 0ull && !exhausted) {
+            if (pool_next == pool_end) {
+                const int leader = __ffsll((long long)mask) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(work, RT_CHUNK);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                pool_next = base < npaths ? base : npaths;
+                pool_end = (base + RT_CHUNK) < npaths ? (base + RT_CHUNK) : npaths;
+                if (base >= npaths) exhausted = true;
+            }
+            if (!exhausted) {
+                if (!alive) {
+                    const uint32_t mine = pool_next + (uint32_t)__popcll(mask & lt_mask);
+                    if (mine < pool_end) {
+                        slot = mine;
+                        pix = mine % npix;
+                        smp = sample0 + mine / npix;
+                        Rng rng = rng_make(seed, pix, smp, 0u);
+                        camera_ray(cam, pix % cam.width, pix / cam.width, rng, o, d);
+                        ctr = rng.ctr;
+                        beta = mk(1.0, 1.0, 1.0);
+                        depth = 0;
+                        alive = true;
+                    }
+                }
+                const uint32_t want = pool_next + (uint32_t)__popcll(mask);
+                pool_next = want < pool_end ? want : pool_end;
+            }
+        }
+        if (__ballot(alive) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (alive) {
+            RayVal src; src.o = o; src.d = d;
+            Ray w = src.world();
+            rays++;
+            RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32); rp.pixel = pix; rp.sample = smp; rp.ctr = ctr;
+            Best b = closest_hit<COUNT, true>(S, src, 0.001, RT_INF, L, rp, tally);
+            V3 lum = mk(0, 0, 0);
+            if (b.ref == RT_NO_HIT) {
+                lum = beta * mk(bgr, bgg, bgb);
+                alive = false;
+            } else {
+                Rec rec = finalize<false>(S, w, b);
+                Rng rng = rng_make(seed, pix, smp, rp.ctr);
+                V3 nd, att, emit;
+                const rt_material m = S.mats[rec.mat];
+                if (!scatter(S, m, w.d, rec, rng, nd, att, emit)) {
+                    lum = beta * emit;
+                    alive = false;
+                } else if (depth + 1u == max_depth) {
+                    alive = false;  // the scattered ray would be traced with depth 0: black (camera.rs:350-352)
+                } else {
+                    beta = beta * att;
+                    o = rec.p;
+                    d = nd;
+                    ctr = rng.ctr;
+                    depth++;
+                    deepest = deepest > depth ? deepest : depth;
+                }
+            }
+            if (!alive) { lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z; }
+        }
+    }
+    unsigned long long r = rays;
+    uint32_t dp = deepest;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        uint32_t other = __shfl_down(dp, off);
+        dp = dp > other ? dp : other;
+    }
+    if (lane == 0) { atomicAdd(&counters[0], r); atomicMax(&counters[1], (unsigned long long)dp); }
+    if (COUNT) tally_flush(tally, tallies);
+}
+
 // Full HitRecord of every ray of a caller-supplied batch from its closest hit (Hittable::hit's out-parameter).
 __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8_t* hit, uint32_t* prim, double* t,
                                  double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out) {
@@ -381,6 +481,7 @@ struct rt_scene {
     uint32_t levels = 0;  // interval slots per lane the walk needs
     bool has_bvh = false; // selects the traverse kernel: lockstep (no BVH entries) or persistent
     uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
+    uint32_t path_waves = 0;     // the same for the whole-path kernel
     std::vector<void*> allocs;
     DScene d;
     const uint4* nodes_nocull = nullptr;  // the tree with every cull box infinite (RT_FLAG_NO_CULL)
@@ -657,7 +758,17 @@ int rt_scene_commit(rt_scene* s, int device) {
         const double everything[6] = {-RT_INF, RT_INF, -RT_INF, RT_INF, -RT_INF, RT_INF};
         std::vector<uint4> rec((size_t)8 * s->nodes.size(), make_uint4(0, 0, 0, 0)), rec_nc;
         for (size_t i = 0; i < s->nodes.size(); ++i) {
-            const rt_node& n = s->nodes[i];
+            rt_node n = s->nodes[i];
+            if (n.kind == RT_NODE_MEDIUM) {
+                // count = 1 marks a boundary of nothing but spheres, quads and triangles, whose two hits the walk
+                // can find in one pass
+                bool flat = true;
+                for (uint32_t j = (uint32_t)i + 1u; j < n.skip; ++j) {
+                    const uint8_t k = s->nodes[j].kind;
+                    flat = flat && (k == RT_NODE_SPHERES || k == RT_NODE_QUADS || k == RT_NODE_TRIANGLES || k == RT_NODE_CULL);
+                }
+                n.count = flat ? 1u : 0u;
+            }
             std::memcpy(&rec[8 * i], &n, sizeof(rt_node));
             if (n.kind == RT_NODE_BVH) {
                 std::memcpy(&rec[8 * i + 1], &s->boxes[(size_t)6 * n.first], 48);
@@ -716,6 +827,10 @@ int rt_scene_commit(rt_scene* s, int device) {
                                                              (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
         if (per_cu < 1) per_cu = 1;
         s->persist_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false>, TRAV_BLOCK,
+                                                             (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
+        if (per_cu < 1) per_cu = 1;
+        s->path_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }
     s->committed = true;
     return RT_OK;
@@ -851,14 +966,16 @@ static int ws_queue(rt_scene* s, Queue& q, size_t n) {
 static int ensure_workspace(rt_scene* s, size_t paths, size_t lum) {
     if (s->ws_paths >= paths && s->ws_lum >= lum) return RT_OK;
     free_list(s->ws_allocs);
-    s->ws_paths = 0;
-    s->ws_lum = 0;
     int rc;
-    if ((rc = ws_queue(s, s->qa, paths))) return rc;
-    if ((rc = ws_queue(s, s->qb, paths))) return rc;
-    HIP_TRY(hipMalloc((void**)&s->hb.t, paths * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
-    HIP_TRY(hipMalloc((void**)&s->hb.ref, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
-    HIP_TRY(hipMalloc((void**)&s->hb.chain, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
+    paths = std::max(paths, s->ws_paths);  // what is freed above is allocated again, never less
+    lum = std::max(lum, s->ws_lum);
+    if (paths) {
+        if ((rc = ws_queue(s, s->qa, paths))) return rc;
+        if ((rc = ws_queue(s, s->qb, paths))) return rc;
+        HIP_TRY(hipMalloc((void**)&s->hb.t, paths * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
+        HIP_TRY(hipMalloc((void**)&s->hb.ref, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
+        HIP_TRY(hipMalloc((void**)&s->hb.chain, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
+    }
     HIP_TRY(hipMalloc((void**)&s->lum_r, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
     HIP_TRY(hipMalloc((void**)&s->lum_g, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
     HIP_TRY(hipMalloc((void**)&s->lum_b, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
@@ -901,7 +1018,56 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                        (o->max_depth == 0 && o->spp_count > 0) ? 0.0 : -0.0);
     if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 64, sm));
 
-    if (o->max_depth > 0 && o->spp_count > 0) {
+    const bool fused = !s->has_bvh && (o->flags & RT_FLAG_WHOLE_PATHS) != 0;
+    if (o->max_depth > 0 && o->spp_count > 0 && fused) {
+        // whole paths in one kernel, batch after batch; a batch is as many samples of every pixel as fit the budget
+        const uint64_t budget = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (32ull << 20), npix);
+        const uint32_t spb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, budget / npix), o->spp_count);
+        const uint64_t bsize = (uint64_t)spb * npix;
+        if (bsize > 0xFFFFFFFFull - RT_CHUNK * 0x10000ull) return fail(RT_ERR_LIMIT, "batch too large");
+        if ((rc = ensure_workspace(s, 0, (size_t)bsize))) return rc;
+        const uint32_t nbatches = (o->spp_count + spb - 1) / spb;
+        HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));  // rays traced, deepest bounce
+        const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
+        DScene d = s->d;
+        if (nocull) d.nodes = s->nodes_nocull;
+        std::vector<hipEvent_t> evs(2 * (size_t)nbatches, nullptr);
+        int rc2 = RT_OK;
+        for (uint32_t b = 0; b < nbatches && rc2 == RT_OK; ++b) {
+            const uint32_t ns = std::min(spb, o->spp_count - b * spb), nb = ns * npix;
+            const uint32_t grid = std::min((nb + TRAV_BLOCK - 1) / TRAV_BLOCK, s->path_waves);
+            hipError_t e = hipEventCreate(&evs[2 * b]);
+            if (e == hipSuccess) e = hipEventCreate(&evs[2 * b + 1]);
+            if (e == hipSuccess) e = hipMemsetAsync(s->d_count + 4, 0, 4, sm);
+            if (e == hipSuccess) e = hipEventRecord(evs[2 * b], sm);
+            if (e != hipSuccess) { rc2 = fail(RT_ERR_DEVICE, "path batch set-up: %s", hipGetErrorString(e)); break; }
+#define PATH_ARGS d, *cam, o->seed, npix, o->spp_begin + b * spb, nb, o->max_depth, o->background[0], o->background[1], \
+                  o->background[2], s->lum_r, s->lum_g, s->lum_b, s->d_count + 4, (unsigned long long*)(s->d_count + 8), s->d_tallies
+            if (count) hipLaunchKernelGGL(k_paths_lockstep<true>, dim3(grid), dim3(TRAV_BLOCK), levels_lds(s, TRAV_BLOCK), sm, PATH_ARGS);
+            else hipLaunchKernelGGL(k_paths_lockstep<false>, dim3(grid), dim3(TRAV_BLOCK), levels_lds(s, TRAV_BLOCK), sm, PATH_ARGS);
+#undef PATH_ARGS
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(evs[2 * b + 1], sm);
+            if (e != hipSuccess) { rc2 = fail(RT_ERR_DEVICE, "path kernel: %s", hipGetErrorString(e)); break; }
+            hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r, s->lum_g, s->lum_b,
+                               npix, ns, film);
+            st.paths += nb;
+            st.path_launches++;
+        }
+        hipError_t e = hipStreamSynchronize(sm);
+        if (rc2 == RT_OK && e != hipSuccess) rc2 = fail(RT_ERR_DEVICE, "path kernels: %s", hipGetErrorString(e));
+        for (uint32_t b = 0; b < nbatches; ++b) {
+            float ms = 0;
+            if (rc2 == RT_OK && evs[2 * b + 1] && hipEventElapsedTime(&ms, evs[2 * b], evs[2 * b + 1]) == hipSuccess) st.ms_paths += ms;
+            if (evs[2 * b]) (void)hipEventDestroy(evs[2 * b]);
+            if (evs[2 * b + 1]) (void)hipEventDestroy(evs[2 * b + 1]);
+        }
+        if (rc2 != RT_OK) return rc2;
+        unsigned long long h[2];
+        HIP_TRY(hipMemcpy(h, s->d_count + 8, 16, hipMemcpyDeviceToHost));
+        st.rays = h[0];
+        st.bounces = (uint32_t)h[1] + 1u;
+    } else if (o->max_depth > 0 && o->spp_count > 0) {
         const uint64_t qcap_want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (32ull << 20), npix);
         uint32_t spb = (uint32_t)std::max<uint64_t>(1, (qcap_want / 4) / npix);  // samples per batch
         spb = std::min(spb, o->spp_count);

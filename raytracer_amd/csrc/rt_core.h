@@ -238,15 +238,14 @@ struct Tally {
 // `first` are then fetched once per wavefront with scalar loads instead of once per lane.
 #if defined(__HIP_DEVICE_COMPILE__)
 RT_HD uint32_t wave_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-RT_HD bool wave_all(bool p) { return __all(p) != 0; }
 RT_HD bool wave_uniform(uint32_t x, uint32_t& first) {
     first = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
     return __all(x == first) != 0;
 }
 #else
 inline bool& host_uniform_mode() { static bool m = true; return m; }  // lets CPU tests take either branch
+inline unsigned long long& host_fallback_count() { static unsigned long long n = 0; return n; }  // for the host tests
 RT_HD uint32_t wave_first(uint32_t x) { return x; }
-RT_HD bool wave_all(bool p) { return p && host_uniform_mode(); }  // "divergent" mode: some other lane always disagrees
 RT_HD bool wave_uniform(uint32_t x, uint32_t& first) { first = x; return host_uniform_mode(); }
 #endif
 
@@ -445,6 +444,122 @@ RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels
     return n.skip;
 }
 
+template <bool MEDIA, bool COUNT, bool LOCKSTEP, class Src>
+RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, const Levels& L, RngPos& rng, Best& best,
+                Ray& cur, uint32_t& cur_chain, Tally& tally);
+
+// ConstantMedium::hit's two boundary hits (constant_medium.rs:55-63): boundary.hit over (-inf, inf), then over
+// (t1 + 0.0001, inf).  Returns false when either misses.
+template <bool COUNT, bool LOCKSTEP, class Src>
+RT_HD bool boundary_two_passes(const DScene& S, const Src& src, uint32_t i, const Node& n, const Levels& L, RngPos& rng,
+                               Ray& cur, uint32_t& cur_chain, Tally& tally, double& t1, double& t2) {
+    double lo = -RT_INF;
+    bool ok = true;
+    for (int pass = 0; pass < 2 && ok; ++pass) {
+        Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
+        lv_set(L, n.level + 1u, lo, RT_INF);
+        walk<false, COUNT, LOCKSTEP>(S, src, i + 1u, n.skip, L, rng, b, cur, cur_chain, tally);
+        ok = b.ref != RT_NO_HIT;
+        if (pass == 0) t1 = b.t; else t2 = b.t;
+        lo = b.t + 0.0001;
+    }
+    return ok;
+}
+
+// The same two values from ONE pass over a boundary that is nothing but spheres, quads and triangles (no BVH, no
+// quadric): each primitive's hit parameter does not depend on the interval it is tested against, only whether it is
+// accepted does, so the first pass returns the smallest parameter m1 any primitive offers and the second the
+// smallest one that is >= m1 + 0.0001 (every hit() accepts start <= t).  A sphere offers both roots: Sphere::hit
+// falls back to the far root when the near one is outside the interval (sphere.rs:52-58).  While scanning, a value
+// within 0.0001 above the minimum so far is set aside; if the minimum drops afterwards, such a value may have been
+// the second hit after all, and `lost` tells the caller to do the two passes instead (two boundary hits closer
+// than 0.0001: edges and corners).
+struct TwoMin {
+    double m1, m2;
+    bool dirty, lost;
+};
+RT_HD void two_min_add(TwoMin& w, double t) {
+    if (t < w.m1) {
+        if (w.dirty) w.lost = true;
+        if (w.m1 >= t + 0.0001) w.m2 = w.m1;  // the old minimum is at most the old second
+        else w.dirty = true;
+        w.m1 = t;
+    } else if (t >= w.m1 + 0.0001) {
+        w.m2 = fmin(w.m2, t);
+    } else {
+        w.dirty = true;
+    }
+}
+template <bool COUNT, bool LOCKSTEP, class Src>
+RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const Node& n, Ray& cur, uint32_t& cur_chain,
+                             Tally& tally, double& t1, double& t2, bool& lost) {
+    TwoMin w; w.m1 = RT_INF; w.m2 = RT_INF; w.dirty = false; w.lost = false;
+    uint32_t tests = 0, bytes = 0;
+    for (uint32_t j = i + 1u; j < n.skip;) {
+        const Node r = load_node(S, LOCKSTEP ? wave_first(j) : j);
+        if (r.chain != cur_chain) { cur = ray_in_chain(S, src.world(), r.chain); cur_chain = r.chain; }
+        if (r.kind == RT_NODE_CULL) {
+            if (LOCKSTEP) j = j + 1u;
+            else j = cull_pass<COUNT>(S, j, 1u, cur, -RT_INF, RT_INF, tally) ? j + 1u : r.skip;
+            continue;
+        }
+        const uint32_t last = r.first + r.count;
+        if (r.kind == RT_NODE_SPHERES) {
+            const double2* base = reinterpret_cast<const double2*>(S.spheres);
+            for (uint32_t k = r.first; k < last; ++k) {
+                const double2 a0 = base[2u * k], a1 = base[2u * k + 1u];
+                V3 oc = mk(a0.x, a0.y, a1.x) - cur.o;
+                double h = dot(oc, cur.d);
+                double c = len2(oc) - a1.y * a1.y;
+                double disc = h * h - cur.a * c;
+                if (!(disc < 0.0)) {
+                    double sq = sqrt(disc);
+                    double r1 = (h - sq) / cur.a, r2 = (h + sq) / cur.a;
+                    if (-RT_INF <= r1 && r1 < RT_INF) two_min_add(w, r1);
+                    if (-RT_INF <= r2 && r2 < RT_INF) two_min_add(w, r2);
+                }
+            }
+            if (COUNT) { tests += r.count; bytes += 40u * r.count; }
+        } else {
+            const bool is_tri = r.kind == RT_NODE_TRIANGLES;
+            const double2* base = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads);
+            for (uint32_t k = r.first; k < last; ++k) {
+                double t;
+                if (planar_t(load_planar(base + 8u * k), is_tri, cur, -RT_INF, RT_INF, t)) two_min_add(w, t);
+            }
+            if (COUNT) { tests += r.count; bytes += 136u * r.count; }
+        }
+        j = j + 1u;
+    }
+    const bool first = w.m1 < RT_INF;
+    if (COUNT) {  // what the two passes would have tested: the second runs only after a first hit
+        tally.prim_tests += first ? 2u * tests : tests;
+        tally.prim_bytes += first ? 2u * bytes : bytes;
+    }
+    if (first && w.m1 >= w.m1 + 0.0001) w.m2 = fmin(w.m2, w.m1);  // 0.0001 below the spacing of doubles at m1
+    t1 = w.m1;
+    t2 = w.m2;
+    lost = w.lost;
+    return first && w.m2 < RT_INF;
+}
+// Dispatch: entries of a MEDIUM record with count == 1 have a boundary the one-pass scan can handle (set where the
+// device records are built).
+template <bool COUNT, bool LOCKSTEP, class Src>
+RT_HD bool boundary_hits(const DScene& S, const Src& src, uint32_t i, const Node& n, const Levels& L, RngPos& rng,
+                         Ray& cur, uint32_t& cur_chain, Tally& tally, double& t1, double& t2) {
+    if (n.count == 1u) {
+        bool lost;
+        bool ok = boundary_one_pass<COUNT, LOCKSTEP>(S, src, i, n, cur, cur_chain, tally, t1, t2, lost);
+        if (!lost) return ok;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        host_fallback_count()++;
+#endif
+        Tally unused; unused.node_tests = 0; unused.prim_tests = 0; unused.prim_bytes = 0; unused.cull_tests = 0;
+        return boundary_two_passes<false, LOCKSTEP>(S, src, i, n, L, rng, cur, cur_chain, unused, t1, t2);
+    }
+    return boundary_two_passes<COUNT, LOCKSTEP>(S, src, i, n, L, rng, cur, cur_chain, tally, t1, t2);
+}
+
 // Walks entries [i, iend) of the flattened tree in order, which is the order of the reference's recursion:
 // HittableSlice::hit in list order with the interval end shrunk to the closest hit so far
 // (hittable_list.rs:88-102), BVHNode::hit narrowing the interval by its box and handing it to left, then right
@@ -457,12 +572,11 @@ RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels
 //
 // LOCKSTEP = true is for trees without BVH entries: every lane then visits the same entries in the same order, so
 // the per-lane branches are dropped and all scene data comes through scalar loads.
-//
-// `mute` (LOCKSTEP only): a lane whose ray fails a CULL entry's box cannot leave the common sequence, so it sits out
-// every entry below `mute` instead.
+// CULL entries are passed over there without testing: a lane that failed the box could not leave the common
+// sequence anyway, and incoherent rays practically never fail it all together.
 template <bool MEDIA, bool COUNT, bool LOCKSTEP, class Src>
 RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, const Levels& L, RngPos& rng, Best& best,
-                Ray& cur, uint32_t& cur_chain, uint32_t& mute, Tally& tally) {
+                Ray& cur, uint32_t& cur_chain, Tally& tally) {
     for (;;) {
         Node n;
         n.kind = RT_NODE_BVH; n.level = 0; n.chain = 0; n.skip = 0; n.first = 0; n.count = 0;
@@ -486,31 +600,18 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
         if (n.chain != cur_chain) { cur = ray_in_chain(S, src.world(), n.chain); cur_chain = n.chain; }
         const double2 iv = lv_get(L, n.level);
         const double s = iv.x, e = fmin(iv.y, best.t);
-        const bool active = !LOCKSTEP || i >= mute;
         if (n.kind == RT_NODE_CULL) {
-            if (LOCKSTEP) {
-                if (active && !cull_pass<COUNT>(S, wave_first(i), 1u, cur, s, e, tally)) mute = n.skip;
-                i = wave_all(mute >= n.skip) ? n.skip : i + 1u;
-            } else {
-                i = cull_pass<COUNT>(S, i, 1u, cur, s, e, tally) ? i + 1u : n.skip;
-            }
+            if (LOCKSTEP) i = i + 1u;
+            else i = cull_pass<COUNT>(S, i, 1u, cur, s, e, tally) ? i + 1u : n.skip;
         } else if (n.kind == RT_NODE_MEDIUM) {
-            if constexpr (MEDIA) if (active) {
+            if constexpr (MEDIA) {
                 // ConstantMedium::hit, constant_medium.rs:46-93
                 if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
                 const rt_medium m = S.media[n.first];
                 const double ray_length = sqrt(cur.a);  // of the ray the medium itself receives
-                double t1 = 0.0, t2 = 0.0, lo = -RT_INF;
-                bool ok = true;
-                for (int pass = 0; pass < 2 && ok; ++pass) {
-                    Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
-                    lv_set(L, n.level + 1u, lo, RT_INF);
-                    walk<false, COUNT, LOCKSTEP>(S, src, i + 1u, n.skip, L, rng, b, cur, cur_chain, mute, tally);
-                    ok = b.ref != RT_NO_HIT;
-                    if (pass == 0) t1 = b.t; else t2 = b.t;
-                    lo = b.t + 0.0001;
-                }
-                if (ok) {
+                double t1 = 0.0, t2 = 0.0;
+                const uint32_t i0 = LOCKSTEP ? wave_first(i) : i;
+                if (boundary_hits<COUNT, LOCKSTEP>(S, src, i0, n, L, rng, cur, cur_chain, tally, t1, t2)) {
                     t1 = fmax(t1, s);
                     t2 = fmin(t2, e);
                     t1 = fmax(t1, 0.0);
@@ -533,7 +634,7 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
                 // all lanes stand on the same run (top-level lists, shared leaves): the entry and its records are
                 // addressed by a wavefront-uniform index and fetched with scalar loads
                 const Node nu = load_node(S, i0);
-                if (active) run_prims<COUNT>(S, nu.kind, nu.first, nu.count, nu.chain, cur, s, e, best, tally);
+                run_prims<COUNT>(S, nu.kind, nu.first, nu.count, nu.chain, cur, s, e, best, tally);
             } else {
                 run_prims<COUNT>(S, n.kind, n.first, n.count, n.chain, cur, s, e, best, tally);
             }
@@ -549,8 +650,8 @@ RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax
     Best best; best.t = RT_INF; best.ref = RT_NO_HIT; best.chain = 0;
     lv_set(L, 0u, tmin, tmax);
     Ray cur = src.world();
-    uint32_t cur_chain = 0, mute = 0;
-    walk<true, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, mute, tally);
+    uint32_t cur_chain = 0;
+    walk<true, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
     return best;
 }
 
@@ -620,18 +721,8 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
         const rt_medium m = S.media[n.first];
         const double ray_length = sqrt(ln.cur.a);
-        double t1 = 0.0, t2 = 0.0, lo = -RT_INF;
-        bool ok = true;
-        for (int pass = 0; pass < 2 && ok; ++pass) {
-            Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
-            lv_set(L, n.level + 1u, lo, RT_INF);
-            uint32_t mute = 0;
-            walk<false, COUNT, false>(S, src, ln.i + 1u, n.skip, L, rng, b, ln.cur, ln.cur_chain, mute, tally);
-            ok = b.ref != RT_NO_HIT;
-            if (pass == 0) t1 = b.t; else t2 = b.t;
-            lo = b.t + 0.0001;
-        }
-        if (ok) {
+        double t1 = 0.0, t2 = 0.0;
+        if (boundary_hits<COUNT, false>(S, src, ln.i, n, L, rng, ln.cur, ln.cur_chain, tally, t1, t2)) {
             t1 = fmax(t1, s);
             t2 = fmin(t2, e);
             t1 = fmax(t1, 0.0);

@@ -16,8 +16,9 @@ def _opts(spp_begin, spp_count, max_depth, seed, background, batch_paths=0, flag
     return o
 
 
-def _flags(counters, cull):
-    return (_lib.RT_FLAG_COUNTERS if counters else 0) | (0 if cull else _lib.RT_FLAG_NO_CULL)
+def _flags(counters, cull, whole_paths):
+    return ((_lib.RT_FLAG_COUNTERS if counters else 0) | (0 if cull else _lib.RT_FLAG_NO_CULL) |
+            (_lib.RT_FLAG_WHOLE_PATHS if whole_paths else 0))
 
 
 def _stats_dict(st):
@@ -65,20 +66,22 @@ class Scene:
         return out
 
     def render(self, cam, spp, max_depth, background, seed=42, spp_begin=0, batch_paths=0, counters=False,
-               cull=True):
+               cull=True, whole_paths=False):
         """Camera::render: returns (film of radiance SUMS, shape (H, W, 3), stats dict).  cull=False switches the
-        cull boxes off: the same film from exactly the box and primitive tests the reference performs."""
+        cull boxes off: the same film from exactly the box and primitive tests the reference performs.
+        whole_paths=True traces whole paths in one kernel instead of the queue-based schedule (scenes without BVH
+        entries only)."""
         film = np.zeros((cam.height, cam.width, 3))
         st = rt_stats()
-        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull))
+        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths))
         self._ck(self.L.rt_render(self.h, C.byref(cam), C.byref(o), film.ctypes.data, C.byref(st)))
         return film, _stats_dict(st)
 
     def render_into(self, cam, spp, max_depth, background, film_device_ptr, seed=42, spp_begin=0, batch_paths=0,
-                    counters=False, cull=True):
+                    counters=False, cull=True, whole_paths=False):
         """Same, into a caller-owned device buffer of H*W*3 f64 (e.g. a torch tensor's data_ptr())."""
         st = rt_stats()
-        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull))
+        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths))
         self._ck(self.L.rt_render_device(self.h, C.byref(cam), C.byref(o), film_device_ptr, C.byref(st)))
         return _stats_dict(st)
 

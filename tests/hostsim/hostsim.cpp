@@ -22,13 +22,22 @@ struct sim_scene {  // host pointers to the arrays of a flattened scene
 
 static std::vector<uint4> g_records;
 static int use_cull = 1;  // 0: every cull box infinite, as under RT_FLAG_NO_CULL
+static int use_one_pass = 1;  // 0: media always take their two boundary hits in two passes
 static DScene to_dscene(const sim_scene* s) {
     DScene d;
     const double everything[6] = {-RT_INF, RT_INF, -RT_INF, RT_INF, -RT_INF, RT_INF};
     const bool cull = use_cull && s->cull_boxes;
     g_records.assign((size_t)8 * s->n_nodes, make_uint4(0, 0, 0, 0));
     for (uint64_t i = 0; i < s->n_nodes; ++i) {
-        const rt_node& n = s->nodes[i];
+        rt_node n = s->nodes[i];
+        if (n.kind == RT_NODE_MEDIUM) {  // as rt_scene_commit marks them: count = 1 for a boundary of plain primitives
+            bool flat = use_one_pass != 0;
+            for (uint32_t j = (uint32_t)i + 1u; j < n.skip; ++j) {
+                const uint8_t k = s->nodes[j].kind;
+                flat = flat && (k == RT_NODE_SPHERES || k == RT_NODE_QUADS || k == RT_NODE_TRIANGLES || k == RT_NODE_CULL);
+            }
+            n.count = flat ? 1u : 0u;
+        }
         std::memcpy(&g_records[8 * i], &n, sizeof(rt_node));
         if (n.kind == RT_NODE_BVH) {
             std::memcpy(&g_records[8 * i + 1], s->boxes + 6 * n.first, 48);
@@ -55,6 +64,8 @@ static int mode = 0;  // 0 generic walk, 1 lockstep walk, 2 per-lane state machi
 extern "C" void sim_set_uniform_mode(int on) { host_uniform_mode() = on != 0; }
 extern "C" void sim_set_walk_mode(int m) { mode = m; }
 extern "C" void sim_set_cull(int on) { use_cull = on; }
+extern "C" void sim_set_one_pass(int on) { use_one_pass = on; }
+extern "C" unsigned long long sim_fallbacks(void) { return host_fallback_count(); }
 
 extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o3, const double* d3, const double* tmin,
                              const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim, double* t,

@@ -1,6 +1,8 @@
 """The per-lane device functions of raytracer_amd/csrc/rt_core.h (tree walk in its three forms, hit-record
 reconstruction, materials, textures, camera), compiled for the host by tests/hostsim and compared with the oracle
 bit for bit.  This is a logic check that runs without a GPU; the GPU tests repeat it on the real kernels."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -24,19 +26,16 @@ def pairs():
 
 
 @pytest.mark.parametrize("cfg", CONFIGS)
-@pytest.mark.parametrize("mode", ["generic-uniform", "generic-divergent", "lockstep", "lockstep-muted",
-                                  "lane-state-machine"])
+@pytest.mark.parametrize("mode", ["generic-uniform", "generic-divergent", "lockstep", "lane-state-machine"])
 def test_walk_matches_oracle(pairs, cfg, mode):
     """Every form of the walk returns the oracle's hits with the cull boxes in use; with the cull boxes switched
-    off it also performs exactly the oracle's box and primitive tests.  ("lockstep-muted": a lane that fails a cull
-    box stays in the common sequence and sits the subtree out, as when other lanes of its wavefront pass.)"""
+    off it also performs exactly the oracle's box and primitive tests."""
     hs, os_, sim = pairs(cfg)
     if mode.startswith("lockstep") and cfg in ("C1", "C4", "C5"):
         pytest.skip("the lockstep walk is only used for trees without BVH entries")
     L = helpers._sim_lib()
-    L.sim_set_walk_mode({"generic-uniform": 0, "generic-divergent": 0, "lockstep": 1, "lockstep-muted": 1,
-                         "lane-state-machine": 2}[mode])
-    L.sim_set_uniform_mode(0 if mode in ("generic-divergent", "lockstep-muted") else 1)
+    L.sim_set_walk_mode({"generic-uniform": 0, "generic-divergent": 0, "lockstep": 1, "lane-state-machine": 2}[mode])
+    L.sim_set_uniform_mode(0 if mode == "generic-divergent" else 1)
     try:
         _, oc = cameras(hs)
         for bounce in (0, 2):
@@ -168,3 +167,103 @@ def test_random_scene_with_every_primitive_and_instance(pairs):
         want = ob.intersect(o, d, 0.001, np.inf, rng3)
         assert want["hit"].mean() > 0.3
         assert_hits_equal(got, want, exact=True, what=f"random scene mode {mode}")
+
+
+def test_media_boundary_hits_through_edges_corners_and_tangents():
+    """The one-pass scan for a medium's two boundary hits against the oracle's two hit() calls, on rays chosen to
+    land two boundary hits within 0.0001 of each other (box edges and corners, sphere tangents, rays starting on a
+    face), where the scan has to notice that it cannot decide and fall back to two passes."""
+    from oracle import oracle as orc
+    from raytracer_amd import HostBuilder
+
+    def make(b):
+        m = b.mat_lambertian(b.tex_solid(0.5, 0.5, 0.5))
+        world = b.list_new()
+        box = b.slice(b.box((0.0, 0.0, 0.0), (2.0, 3.0, 4.0), m))
+        b.list_add(world, b.constant_medium(b.translate(b.rotate_y(box, 30.0), (1.0, 0.5, -2.0)), 0.8, b.tex_solid(1, 1, 1)))
+        b.list_add(world, b.constant_medium(b.sphere((6.0, 1.0, 0.0), 1.5, m), 0.5, b.tex_solid(0, 0, 1)))
+        two = b.list_new()   # a boundary of two overlapping spheres and a triangle: several candidates per ray
+        b.list_add(two, b.sphere((-5.0, 0.0, 0.0), 1.0, m))
+        b.list_add(two, b.sphere((-4.2, 0.0, 0.0), 1.0, m))
+        b.list_add(two, b.triangle((-6.0, -1.0, 0.3), (3.0, 0.0, 0.0), (0.0, 2.5, 0.0), m))
+        b.list_add(world, b.constant_medium(b.slice(two), 0.7, b.tex_solid(0, 1, 0)))
+        b.list_add(world, b.quad((-20.0, -5.0, -20.0), (40.0, 0.0, 0.0), (0.0, 0.0, 40.0), m))
+        b.set_world(b.slice(world))
+
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    make(hb)
+    make(ob)
+    sim = HostSim(hb)
+    rs = np.random.RandomState(11)
+    th = np.deg2rad(30.0)
+    corners = []
+    for x in (0.0, 2.0):
+        for y in (0.0, 3.0):
+            for z in (0.0, 4.0):  # object -> world: RotateY then Translate
+                corners.append((np.cos(th) * x + np.sin(th) * z + 1.0, y + 0.5, -np.sin(th) * x + np.cos(th) * z - 2.0))
+    corners = np.array(corners)
+    targets = [corners]
+    for a in range(8):
+        for b_ in range(a + 1, 8):
+            if np.isclose(np.abs(corners[a] - corners[b_]).sum(), 0) or (np.count_nonzero(np.abs(corners[a] - corners[b_]) > 1e-9) > 2 and False):
+                continue
+            f = rs.uniform(0, 1, (6, 1))
+            targets.append(corners[a] * f + corners[b_] * (1 - f))   # points on edges and diagonals
+    targets = np.concatenate(targets)
+    # tangents to the spheres: points on the silhouette circle seen from the origin of each ray
+    o_list, d_list = [], []
+    for tgt in targets:
+        for _ in range(6):
+            o = rs.uniform(-12, 12, 3)
+            o_list.append(o)
+            d_list.append((tgt - o) * (1.0 + 1e-9 * rs.standard_normal()))
+            o_list.append(o)
+            d_list.append((tgt - o) + 1e-6 * rs.standard_normal(3))   # within 0.0001 of the edge
+    for c, r in (((6.0, 1.0, 0.0), 1.5), ((-5.0, 0.0, 0.0), 1.0), ((-4.2, 0.0, 0.0), 1.0)):
+        c = np.array(c)
+        for _ in range(300):
+            o = c + rs.standard_normal(3) * 6.0
+            oc = c - o
+            dist = np.linalg.norm(oc)
+            if dist <= r * 1.01:
+                continue
+            # a direction on the tangent cone, nudged in or out by up to ~1e-7
+            perp = np.cross(oc, rs.standard_normal(3))
+            perp /= np.linalg.norm(perp)
+            ang = np.arcsin(r / dist) + rs.choice([0.0, 1e-7, -1e-7, 3e-5, -3e-5])
+            o_list.append(o)
+            d_list.append(np.cos(ang) * oc / dist + np.sin(ang) * perp)
+    # rays that start on a face or inside
+    for _ in range(400):
+        p = corners[0] * 0 + np.array([1.0, 0.5, -2.0]) + rs.uniform(0, 1, 3) * np.array([2.0, 3.0, 1.0])
+        o_list.append(p)
+        d_list.append(rs.standard_normal(3))
+    o = np.array(o_list)
+    d = np.array(d_list)
+    n = len(o)
+    rng3 = np.stack([np.arange(n), np.ones(n), np.zeros(n)], axis=1).astype(np.uint32)
+    want = ob.intersect(o, d, 0.001, np.inf, rng3)
+    assert (want["ctr"] > 0).mean() > 0.3     # many rays do cross a medium (a draw is made)
+    L = helpers._sim_lib()
+    L.sim_fallbacks.restype = C.c_ulonglong
+    for mode in (0, 1, 2):
+        L.sim_set_walk_mode(mode)
+        before = L.sim_fallbacks()
+        try:
+            got = sim.intersect(o, d, 0.001, np.inf, rng3)
+            fallbacks = L.sim_fallbacks() - before
+            L.sim_set_one_pass(0)
+            got_two = sim.intersect(o, d, 0.001, np.inf, rng3)
+            assert L.sim_fallbacks() - before == fallbacks
+            sim.set_cull(False)   # the reference's own test counts, whichever way the two hits are found
+            L.sim_set_one_pass(1)
+            got_nc = sim.intersect(o, d, 0.001, np.inf, rng3)
+        finally:
+            sim.set_cull(True)
+            L.sim_set_one_pass(1)
+            L.sim_set_walk_mode(0)
+        assert_hits_equal(got, want, exact=True, what=f"one pass, mode {mode}")
+        assert_hits_equal(got_two, want, exact=True, what=f"two passes, mode {mode}")
+        assert_hits_equal(got_nc, want, exact=True, what=f"one pass without cull boxes, mode {mode}")
+        assert got_nc["counters"]["prim_tests"] == want["counters"]["prim_tests"]
+        assert 0 < fallbacks < 0.2 * n, fallbacks   # the undecidable cases occur here, and stay the exception

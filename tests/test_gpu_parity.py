@@ -90,13 +90,18 @@ def test_per_sample_radiance_matches_oracle(gpu_scenes, cfg):
 
 
 @pytest.mark.parametrize("cfg", CONFIGS)
-def test_wavefront_film_equals_sum_of_samples(gpu_scenes, cfg):
-    """rt_render (wavefront queues + compaction + film accumulation) must give, bit for bit, the in-order sum of the
-    per-sample radiances rt_trace_samples computes with one lane per whole path."""
+@pytest.mark.parametrize("schedule", ["queues", "whole-paths"])
+def test_film_equals_sum_of_samples(gpu_scenes, cfg, schedule):
+    """rt_render must give, bit for bit, the in-order sum of the per-sample radiances rt_trace_samples computes with
+    one lane per whole path -- on both schedules: the queue-based one (queues + compaction + film accumulation) and
+    whole paths in one kernel (on request, for scenes without BVH entries)."""
     hs, os_, scene = gpu_scenes(cfg)
     hc, _ = cameras(hs)
     spp = 3
-    film, stats = scene.render(hc, spp, hs.max_depth, hs.background, spp_begin=5, batch_paths=2 * hc.width * hc.height)
+    film, stats = scene.render(hc, spp, hs.max_depth, hs.background, spp_begin=5, batch_paths=2 * hc.width * hc.height,
+                               whole_paths=schedule == "whole-paths")
+    assert (stats["path_launches"] > 0) == (schedule == "whole-paths" and cfg in ("C2", "C3"))
+    assert (stats["traverse_launches"] > 0) != (stats["path_launches"] > 0)
     npix = hc.width * hc.height
     pixel = np.tile(np.arange(npix, dtype=np.uint32), spp)
     sample = np.repeat(np.arange(5, 5 + spp, dtype=np.uint32), npix)
