@@ -328,7 +328,7 @@ __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8
 // Material::emitted / scatter on the closest hit, throughput update, termination, and compaction of the
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DScene S, uint64_t seed, uint32_t n, Queue q, HitBuf hb,
+__global__ void __launch_bounds__(SHADE_BLOCK, 4) k_shade(DScene S, uint64_t seed, uint32_t n, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
                                                        uint32_t iter, uint32_t max_depth) {

@@ -809,8 +809,8 @@ RT_HD void sphere_uv(V3 p, double& u, double& v) {  // sphere.rs:90-98
 // Rebuilds the HitRecord of the closest hit exactly as the primitive's hit() fills it (sphere.rs:65-73,
 // parallelogram.rs:113-128, triangle.rs:137-152, quadric.rs:56-82, constant_medium.rs:79-90) in the ray space of
 // its chain, then maps p and normal back out through the instances (hittable/mod.rs:88,131-132).
-// FULL = false skips a sphere's acos/atan2 when its material cannot read (u, v): only an image texture does, and a
-// checker may lead to one.
+// FULL = false skips (u, v) when the material cannot read them: only an image texture does, and a checker may lead
+// to one.
 RT_HD bool mat_reads_uv(const DScene& S, uint32_t mat) {
     const rt_material m = S.mats[mat];
     if (m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC) return false;
@@ -836,12 +836,14 @@ RT_HD Rec finalize(const DScene& S, const Ray& wray, const Best& b) {
         case RT_NODE_QUADS:
         case RT_NODE_TRIANGLES: {
             const double* q = (kind == RT_NODE_QUADS ? S.quads : S.tris) + 16u * k;
-            V3 ph = r.p - ld3(q + 4);
-            r.u = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
-            r.v = dot(ld3(q + 13), cross(ld3(q + 7), ph));
-            face_normal(r, ray.d, ld3(q));
             if (kind == RT_NODE_QUADS) { r.mat = S.quad_mat[k]; r.prim_id = S.quad_id[k]; }
             else { r.mat = S.tri_mat[k]; r.prim_id = S.tri_id[k]; }
+            if (FULL || mat_reads_uv(S, r.mat)) {
+                V3 ph = r.p - ld3(q + 4);
+                r.u = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
+                r.v = dot(ld3(q + 13), cross(ld3(q + 7), ph));
+            }
+            face_normal(r, ray.d, ld3(q));
             break;
         }
         case RT_NODE_QUADRICS: {
@@ -907,10 +909,6 @@ RT_HD double perlin_turbulence(const double* vec, const uint32_t* perm, V3 p, in
     }
     return fabs(accum);
 }
-RT_HD bool tex_needs_uv(const DScene& S, uint32_t tid) {
-    // conservative: only image textures read (u, v); a checker may lead to one
-    return S.texs[tid].kind == RT_TEX_IMAGE || S.texs[tid].kind == RT_TEX_CHECKER;
-}
 // Texture::value, texture.rs:25-29 (solid), :59-80 (checker), :116-136 (image), :143-157 (perlin).
 RT_HD V3 tex_value(const DScene& S, uint32_t tid, double u, double v, V3 p) {
     for (int guard = 0; guard < 64; ++guard) {
@@ -953,16 +951,24 @@ RT_HD double reflectance(double cosine, double ri) {  // material.rs:161-166
 RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& rec, Rng& rng, V3& out_d, V3& att,
                    V3& emit) {
     emit = mk(0, 0, 0);
+    // What several materials share is evaluated once, ahead of the switch, so that a wavefront with a mix of
+    // materials runs the rejection loop and the texture code once instead of once per material.  The random unit
+    // vector is the first (and only) thing Lambertian, Metal and Isotropic draw, so the stream is unchanged.
+    const bool wants_tex = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+    const bool wants_ruv = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_ISOTROPIC;
+    V3 tex = mk(0, 0, 0), ruv = mk(0, 0, 0);
+    if (wants_tex) tex = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+    if (wants_ruv) ruv = random_unit_vector(rng);
     switch (m.kind) {
         case RT_MAT_LAMBERTIAN: {  // :45-68
-            V3 temp = rec.n + random_unit_vector(rng);
+            V3 temp = rec.n + ruv;
             out_d = near_zero(temp) ? rec.n : temp;
-            att = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+            att = tex;
             return true;
         }
         case RT_MAT_METAL: {  // :88-104
             V3 reflected = reflect(ray_d, rec.n);
-            out_d = unit(reflected) + (m.param * random_unit_vector(rng));
+            out_d = unit(reflected) + (m.param * ruv);
             att = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
             return true;
         }
@@ -978,12 +984,12 @@ RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& r
             return true;
         }
         case RT_MAT_DIFFUSE_LIGHT: {  // :185-189
-            emit = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+            emit = tex;
             return false;
         }
         default: {  // RT_MAT_ISOTROPIC :196-208
-            out_d = random_unit_vector(rng);
-            att = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+            out_d = ruv;
+            att = tex;
             return true;
         }
     }
