@@ -134,10 +134,12 @@ def main():
         rays_local = sum(s["rays"] for s in stats)
         fused = sum(s["path_launches"] for s in stats) > 0
         if fused:  # whole paths in one kernel: the dominant kernel does the whole bounce
-            kernel, launches, ms_trav, b_kernel = "k_paths_lockstep", sum(s["path_launches"] for s in stats), \
+            kernel = "k_paths_lockstep"
+            launches, ms_trav, b_kernel = sum(s["path_launches"] for s in stats), \
                 sum(s["ms_paths"] for s in stats), b_ray
         else:
-            kernel, launches, ms_trav, b_kernel = "k_traverse_persistent", sum(s["traverse_launches"] for s in stats), \
+            kernel = "k_traverse_lockstep" if stats[0]["lockstep"] else "k_traverse_persistent"
+            launches, ms_trav, b_kernel = sum(s["traverse_launches"] for s in stats), \
                 sum(s["ms_traverse"] for s in stats), b_trav
         avg_launch_ms = ms_trav / launches
         achieved = (rays_local / launches) * b_kernel / (avg_launch_ms * 1e-3) / 1e9

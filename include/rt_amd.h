@@ -56,7 +56,8 @@ typedef struct rt_texture {
     uint32_t kind;
     uint32_t a;
     uint32_t b;
-    uint32_t reserved;
+    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_traverse_lockstep / k_paths_lockstep,
+                          otherwise k_traverse_persistent */
     double color[3];
     double scale;
 } rt_texture;
@@ -68,7 +69,8 @@ enum rt_xform_kind {
 };
 typedef struct rt_xform_op {
     uint32_t kind;
-    uint32_t reserved;
+    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_traverse_lockstep / k_paths_lockstep,
+                          otherwise k_traverse_persistent */
     double v[3];
 } rt_xform_op;
 /* A chain lists the instance transforms between the world and a node, outermost first.  Chain 0 is empty. */
@@ -159,7 +161,8 @@ typedef struct rt_stats {
     uint32_t traverse_launches;
     uint32_t path_launches;
     uint32_t bounces; /* most world.hit calls any one path made */
-    uint32_t reserved;
+    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_traverse_lockstep / k_paths_lockstep,
+                          otherwise k_traverse_persistent */
 } rt_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */

@@ -1011,6 +1011,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     double* film = (double*)film_dev;
     rt_stats st;
     std::memset(&st, 0, sizeof st);
+    st.lockstep = s->has_bvh ? 0u : 1u;
     const bool count = (o->flags & RT_FLAG_COUNTERS) != 0;
     hipStream_t sm = s->stream;
     HIP_TRY(hipEventRecord(s->ev[0], sm));

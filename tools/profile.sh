@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage: tools/profile.sh <config> <spp> <tag>   (run on the GPU box from the repository root)
+# usage: [STEPS=k WARMUP=w] tools/profile.sh <config> <spp> <tag>   (run on the GPU box from the repository root)
 # kernel-trace + stats pass and separate --pmc passes of the same bench command; summaries land in gpurun_out/prof_<tag>/
 cfg=$1; spp=$2; tag=$3
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="python3 $root/bench.py --config $cfg --spp $spp --steps 1 --warmup 0 --no-cpu-baseline"
+cmd="python3 $root/bench.py --config $cfg --spp $spp --steps ${STEPS:-1} --warmup ${WARMUP:-0} --no-cpu-baseline"
 cd /tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $cmd > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 i=0
