@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "rt_core.h"
+#include "rt_records.h"
 
 using namespace rt;
 
@@ -752,44 +753,16 @@ int rt_scene_commit(rt_scene* s, int device) {
     DScene& d = s->d;
     d.n_nodes = (uint32_t)s->nodes.size();
 #define UP(vec, field) if ((rc = upload(s, vec, &d.field))) return rc
-    // tree entries as the kernels read them, one 128-byte record each: header | box of a BVH or CULL entry | cull
-    // box of a BVH entry.  A second copy has every cull box infinite, so that nothing is culled.
+    // tree entries as the kernels read them (rt_records.h), and a second copy with every cull box switched off
     {
-        const double everything[6] = {-RT_INF, RT_INF, -RT_INF, RT_INF, -RT_INF, RT_INF};
-        std::vector<uint4> rec((size_t)8 * s->nodes.size(), make_uint4(0, 0, 0, 0)), rec_nc;
-        for (size_t i = 0; i < s->nodes.size(); ++i) {
-            rt_node n = s->nodes[i];
-            if (n.kind == RT_NODE_MEDIUM) {
-                // count = 1 marks a boundary of nothing but spheres, quads and triangles, whose two hits the walk
-                // can find in one pass
-                bool flat = true;
-                for (uint32_t j = (uint32_t)i + 1u; j < n.skip; ++j) {
-                    const uint8_t k = s->nodes[j].kind;
-                    flat = flat && (k == RT_NODE_SPHERES || k == RT_NODE_QUADS || k == RT_NODE_TRIANGLES || k == RT_NODE_CULL);
-                }
-                n.count = flat ? 1u : 0u;
-            }
-            std::memcpy(&rec[8 * i], &n, sizeof(rt_node));
-            if (n.kind == RT_NODE_BVH) {
-                std::memcpy(&rec[8 * i + 1], &s->boxes[(size_t)6 * n.first], 48);
-                std::memcpy(&rec[8 * i + 4], s->cull_boxes.empty() ? everything : &s->cull_boxes[(size_t)6 * n.first], 48);
-            } else if (n.kind == RT_NODE_CULL) {
-                std::memcpy(&rec[8 * i + 1], &s->boxes[(size_t)6 * n.first], 48);
-            }
-        }
-        rec_nc = rec;
-        for (size_t i = 0; i < s->nodes.size(); ++i) {
-            if (s->nodes[i].kind == RT_NODE_BVH) std::memcpy(&rec_nc[8 * i + 4], everything, 48);
-            else if (s->nodes[i].kind == RT_NODE_CULL) {
-                // a ray whose interval is already empty fails even an infinite box: make failing a no-op
-                rt_node n = s->nodes[i];
-                n.skip = (uint32_t)i + 1u;
-                std::memcpy(&rec_nc[8 * i], &n, sizeof(rt_node));
-                std::memcpy(&rec_nc[8 * i + 1], everything, 48);
-            }
-        }
-        UP(rec, nodes);
-        if ((rc = upload(s, rec_nc, &s->nodes_nocull))) return rc;
+        const double* cb = s->cull_boxes.empty() ? nullptr : s->cull_boxes.data();
+        std::vector<uint32_t> rec = build_records(s->nodes.data(), s->nodes.size(), s->boxes.data(), cb, true, true);
+        std::vector<uint32_t> rec_nc = build_records(s->nodes.data(), s->nodes.size(), s->boxes.data(), cb, false, true);
+        const uint32_t *d_rec = nullptr, *d_rec_nc = nullptr;
+        if ((rc = upload(s, rec, &d_rec))) return rc;
+        if ((rc = upload(s, rec_nc, &d_rec_nc))) return rc;
+        d.nodes = reinterpret_cast<const uint4*>(d_rec);
+        s->nodes_nocull = reinterpret_cast<const uint4*>(d_rec_nc);
     }
     UP(s->spheres, spheres); UP(s->quads, quads); UP(s->tris, tris);
     UP(s->quadrics, quadrics); UP(s->sphere_mat, sphere_mat); UP(s->sphere_id, sphere_id); UP(s->quad_mat, quad_mat);

@@ -250,8 +250,9 @@ RT_HD bool wave_uniform(uint32_t x, uint32_t& first) { first = x; return host_un
 #endif
 
 // AABB::hit, aabb.rs:164-200: narrows (s, e) axis by axis, miss as soon as e <= s.
-RT_HD bool slab(const double2* b, const Ray& r, double& s, double& e) {
-    const double2 bx = b[0], by = b[1], bz = b[2];
+RT_HD bool slab3(const double2 bx, const double2 by, const double2 bz, const Ray& r, double& s, double& e);
+RT_HD bool slab(const double2* b, const Ray& r, double& s, double& e) { return slab3(b[0], b[1], b[2], r, s, e); }
+RT_HD bool slab3(const double2 bx, const double2 by, const double2 bz, const Ray& r, double& s, double& e) {
     {
         double t0 = (bx.x - r.o.x) * r.inv.x, t1 = (bx.y - r.o.x) * r.inv.x;
         if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
@@ -684,36 +685,50 @@ RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const 
 template <bool COUNT, class Src>
 RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Levels& L, RngPos& rng, Tally& tally) {
     if (ln.i >= S.n_nodes) { ln.state = RT_ST_DONE; return; }
-    const Node n = load_node(S, ln.i);
+    // The whole 128-byte record at once, whatever its kind: the boxes and the leaf's run sit in the same cache line
+    // as the header, and fetching them together costs one round trip instead of one per dependent step.
+    const uint4* rp = S.nodes + 8u * ln.i;
+    const double2* bp = reinterpret_cast<const double2*>(rp);
+    const uint4 raw = rp[0];
+    const double2 b0 = bp[1], b1 = bp[2], b2 = bp[3], c0 = bp[4], c1 = bp[5], c2 = bp[6];
+    const uint4 leaf = rp[7];
+    const double2 iv0 = lv_get(L, raw.x >> 8 & 0xFFu);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keeps the compiler from sinking the loads into the branches below, where each would wait on its own
+    asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(c0.x), "v"(c1.x), "v"(c2.x), "v"(leaf.x), "v"(leaf.y), "v"(leaf.z));
+#endif
+    Node n;
+    n.kind = raw.x & 0xFFu; n.level = raw.x >> 8 & 0xFFu; n.chain = raw.x >> 16;
+    n.skip = raw.y; n.first = raw.z; n.count = raw.w;
     if (n.chain != ln.cur_chain) { ln.cur = ray_in_chain(S, src.world(), n.chain); ln.cur_chain = n.chain; }
+    const double s = iv0.x, e = fmin(iv0.y, ln.best.t);
     if (n.kind == RT_NODE_BVH) {
         ray_need_inv(ln.cur);
-        const double2 bv = lv_get(L, n.level);
-        double bs = bv.x, be = fmin(bv.y, ln.best.t);
-        if (COUNT) tally.node_tests++;
-        if (!cull_pass<COUNT>(S, ln.i, 4u, ln.cur, bs, be, tally)) { ln.i = n.skip; return; }
-        if (!slab(reinterpret_cast<const double2*>(S.nodes + 8u * ln.i + 1u), ln.cur, bs, be)) { ln.i = n.skip; return; }
-        if (n.skip == ln.i + 2u) {
+        double bs = s, be = e;
+        if (COUNT) { tally.node_tests++; tally.cull_tests++; }
+        {
+            double cs = s, ce = e;  // the cull box narrows nothing
+            if (!slab3(c0, c1, c2, ln.cur, cs, ce)) { ln.i = n.skip; return; }
+        }
+        if (!slab3(b0, b1, b2, ln.cur, bs, be)) { ln.i = n.skip; return; }
+        if (leaf.x != 0u) {
             // a leaf whose children are one run of primitives (the usual case): go straight to the run with the
             // narrowed interval in registers, without a round trip through the level slots
-            const Node r = load_node(S, ln.i + 1u);
-            if (r.kind >= RT_NODE_SPHERES && r.count > 0u && r.chain == n.chain) {
-                ln.kind = r.kind; ln.k = r.first; ln.kend = r.first + r.count;
-                ln.s = bs; ln.e = be;
-                ln.i = ln.i + 1u;
-                ln.state = RT_ST_RUN;
-                return;
-            }
+            ln.kind = leaf.x; ln.k = leaf.y; ln.kend = leaf.y + leaf.z;
+            ln.s = bs; ln.e = be;
+            ln.i = ln.i + 1u;
+            ln.state = RT_ST_RUN;
+            return;
         }
         lv_set(L, n.level + 1u, bs, be);
         ln.i = ln.i + 1u;
         return;
     }
-    const double2 iv = lv_get(L, n.level);
-    const double s = iv.x, e = fmin(iv.y, ln.best.t);
     if (n.kind == RT_NODE_CULL) {
         ray_need_inv(ln.cur);
-        ln.i = cull_pass<COUNT>(S, ln.i, 1u, ln.cur, s, e, tally) ? ln.i + 1u : n.skip;
+        if (COUNT) tally.cull_tests++;
+        double cs = s, ce = e;
+        ln.i = slab3(b0, b1, b2, ln.cur, cs, ce) ? ln.i + 1u : n.skip;
         return;
     }
     if (n.kind == RT_NODE_MEDIUM) {

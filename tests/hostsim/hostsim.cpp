@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../raytracer_amd/csrc/rt_core.h"
+#include "../../raytracer_amd/csrc/rt_records.h"
 
 using namespace rt;
 
@@ -20,38 +21,13 @@ struct sim_scene {  // host pointers to the arrays of a flattened scene
     const double* cull_boxes;  // one per box, or null
 };
 
-static std::vector<uint4> g_records;
-static int use_cull = 1;  // 0: every cull box infinite, as under RT_FLAG_NO_CULL
+static std::vector<uint32_t> g_records;
+static int use_cull = 1;      // 0: every cull box switched off, as under RT_FLAG_NO_CULL
 static int use_one_pass = 1;  // 0: media always take their two boundary hits in two passes
 static DScene to_dscene(const sim_scene* s) {
     DScene d;
-    const double everything[6] = {-RT_INF, RT_INF, -RT_INF, RT_INF, -RT_INF, RT_INF};
-    const bool cull = use_cull && s->cull_boxes;
-    g_records.assign((size_t)8 * s->n_nodes, make_uint4(0, 0, 0, 0));
-    for (uint64_t i = 0; i < s->n_nodes; ++i) {
-        rt_node n = s->nodes[i];
-        if (n.kind == RT_NODE_MEDIUM) {  // as rt_scene_commit marks them: count = 1 for a boundary of plain primitives
-            bool flat = use_one_pass != 0;
-            for (uint32_t j = (uint32_t)i + 1u; j < n.skip; ++j) {
-                const uint8_t k = s->nodes[j].kind;
-                flat = flat && (k == RT_NODE_SPHERES || k == RT_NODE_QUADS || k == RT_NODE_TRIANGLES || k == RT_NODE_CULL);
-            }
-            n.count = flat ? 1u : 0u;
-        }
-        std::memcpy(&g_records[8 * i], &n, sizeof(rt_node));
-        if (n.kind == RT_NODE_BVH) {
-            std::memcpy(&g_records[8 * i + 1], s->boxes + 6 * n.first, 48);
-            std::memcpy(&g_records[8 * i + 4], cull ? s->cull_boxes + 6 * n.first : everything, 48);
-        } else if (n.kind == RT_NODE_CULL) {
-            std::memcpy(&g_records[8 * i + 1], cull ? s->boxes + 6 * n.first : everything, 48);
-            if (!cull) {  // a ray whose interval is already empty fails even an infinite box: make failing a no-op
-                rt_node m = n;
-                m.skip = (uint32_t)i + 1u;
-                std::memcpy(&g_records[8 * i], &m, sizeof(rt_node));
-            }
-        }
-    }
-    d.nodes = g_records.data(); d.n_nodes = (uint32_t)s->n_nodes; d.spheres = s->spheres; d.quads = s->quads;
+    g_records = build_records(s->nodes, (size_t)s->n_nodes, s->boxes, s->cull_boxes, use_cull != 0, use_one_pass != 0);
+    d.nodes = reinterpret_cast<const uint4*>(g_records.data()); d.n_nodes = (uint32_t)s->n_nodes; d.spheres = s->spheres; d.quads = s->quads;
     d.tris = s->tris; d.quadrics = s->quadrics; d.sphere_mat = s->sphere_mat; d.sphere_id = s->sphere_id;
     d.quad_mat = s->quad_mat; d.quad_id = s->quad_id; d.tri_mat = s->tri_mat; d.tri_id = s->tri_id;
     d.quadric_mat = s->quadric_mat; d.quadric_id = s->quadric_id; d.media = s->media; d.ops = s->ops; d.chains = s->chains;
