@@ -780,16 +780,23 @@ RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
             ln.e = t;
         }
     } else if (ln.kind == RT_NODE_SPHERES) {
+        // up to four spheres per step: their records (32 bytes each) share one 128-byte line
         const double2* rec = reinterpret_cast<const double2*>(S.spheres) + 2u * ln.k;
-        if (COUNT) { tally.prim_tests += two ? 2u : 1u; tally.prim_bytes += two ? 80u : 40u; }
-        if (sphere_t(rec, ln.cur, ln.s, ln.e, t)) {
-            ln.best.t = t; ln.best.ref = make_ref(RT_NODE_SPHERES, ln.k); ln.best.chain = ln.cur_chain;
-            ln.e = t;
+        const uint32_t left = ln.kend - ln.k, done = left < 4u ? left : 4u;
+        double2 q[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) q[j] = rec[j < 2u * done ? j : 0u];
+        if (COUNT) { tally.prim_tests += done; tally.prim_bytes += 40u * done; }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (j < done && sphere_t(q + 2u * j, ln.cur, ln.s, ln.e, t)) {
+                ln.best.t = t; ln.best.ref = make_ref(RT_NODE_SPHERES, ln.k + j); ln.best.chain = ln.cur_chain;
+                ln.e = t;
+            }
         }
-        if (two && sphere_t(rec + 2u, ln.cur, ln.s, ln.e, t)) {
-            ln.best.t = t; ln.best.ref = make_ref(RT_NODE_SPHERES, ln.k + 1u); ln.best.chain = ln.cur_chain;
-            ln.e = t;
-        }
+        ln.k = ln.k + done;
+        if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
+        return;
     } else {
         if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
         if (quadric_t(reinterpret_cast<const double2*>(S.quadrics) + 5u * ln.k, ln.cur, ln.s, ln.e, t)) {
