@@ -50,6 +50,9 @@ int rth_rotate_y(rth_builder* b, int obj, double degrees);          /* RotateY::
 int rth_constant_medium(rth_builder* b, int boundary, double density, int tex); /* ConstantMedium::new */
 int rth_load_model(rth_builder* b, const char* path, double scale, int mat);    /* load_model -> object */
 int rth_bbox(rth_builder* b, int obj, double* out6);
+/* Geometric bounds of the object's possible hit points (x0 x1 y0 y1 z0 z1; +-inf when unbounded, inf/-inf when
+ * empty): what the cull boxes are made from.  Not part of the reference. */
+int rth_extent(rth_builder* b, int obj, double* out6);
 int rth_set_world(rth_builder* b, int obj); /* flattens the tree under obj */
 
 /* flattened arrays of the current world (valid until the next rth_set_world / rth_free) */

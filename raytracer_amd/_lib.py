@@ -144,7 +144,7 @@ def host():
         "rth_y_cylinder": [vp, vp, dbl, i32], "rth_quadric_sphere": [vp, vp, dbl, i32], "rth_y_cone": [vp, vp, vp, i32],
         "rth_list_new": [vp], "rth_list_add": [vp, i32, i32], "rth_box": [vp, vp, vp, i32], "rth_slice": [vp, i32],
         "rth_bvh": [vp, i32], "rth_translate": [vp, i32, vp], "rth_rotate_y": [vp, i32, dbl],
-        "rth_constant_medium": [vp, i32, dbl, i32], "rth_load_model": [vp, cp, dbl, i32], "rth_bbox": [vp, i32, vp],
+        "rth_constant_medium": [vp, i32, dbl, i32], "rth_load_model": [vp, cp, dbl, i32], "rth_bbox": [vp, i32, vp], "rth_extent": [vp, i32, vp],
         "rth_set_world": [vp, i32],
     }
     for name, args in sig.items():

@@ -124,6 +124,12 @@ class HostBuilder:
         self._ck(self.H.rth_bbox(self.b, obj, out))
         return np.array(out[:])
 
+    def extent(self, obj):
+        """Geometric bounds of the object's possible hit points (x0 x1 y0 y1 z0 z1), the source of the cull boxes."""
+        out = (C.c_double * 6)()
+        self._ck(self.H.rth_extent(self.b, obj, out))
+        return np.array(out[:])
+
     def set_world(self, obj):
         self._ck(self.H.rth_set_world(self.b, obj))
 

@@ -1,6 +1,8 @@
 // rt_host_capi.cpp -- C wrapper over the C++ host layer (include/rt_host.h).
 #include "rt_host.h"
 
+#include <cmath>
+
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -132,6 +134,13 @@ int rth_bbox(rth_builder* b, int obj, double* o) {
     OBJ(obj);
     const AABB& bb = b->objects[obj]->bounding_box();
     o[0] = bb.x.start; o[1] = bb.x.end; o[2] = bb.y.start; o[3] = bb.y.end; o[4] = bb.z.start; o[5] = bb.z.end;
+    return 0;
+}
+int rth_extent(rth_builder* b, int obj, double* o) {
+    OBJ(obj);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    b->objects[obj]->extent(lo, hi);
+    for (int c = 0; c < 3; ++c) { o[2 * c] = lo[c]; o[2 * c + 1] = hi[c]; }
     return 0;
 }
 int rth_set_world(rth_builder* b, int obj) {

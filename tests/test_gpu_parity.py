@@ -214,3 +214,52 @@ def test_image_rmse_gpu_vs_oracle_at_equal_spp(gpu_scenes):
         assert rmse < rmse_max, (cfg, rmse)
         assert off < off_max, (cfg, off)
         assert 20 * np.log10(255.0 / max(rmse, 1e-9)) > 36.0  # PSNR
+
+
+def test_full_size_headline_workload_properties():
+    """BASELINE's configs[1] at its full size (cornell_smoke 600x600, 200 spp, 72 M paths), through size-independent
+    properties: the film does not depend on how the work is cut up (queue size, schedule, cull boxes: bit for bit;
+    two half renders: to rounding, since only the association of the sum changes) and repeats exactly."""
+    from raytracer_amd import HostBuilder, camera_new, scenes
+    spec = scenes.build("C2", HostBuilder(), width=600)
+    cam = camera_new(image_width=600, **spec.camera)
+    scene = spec.builder.commit(0)
+    try:
+        spp = 200
+        film, st = scene.render(cam, spp, spec.max_depth, spec.background)
+        assert st["paths"] == 600 * 600 * spp and st["rays"] > 4 * st["paths"]
+        again, st2 = scene.render(cam, spp, spec.max_depth, spec.background)
+        assert np.array_equal(film, again) and st2["rays"] == st["rays"]
+        small_queue, st3 = scene.render(cam, spp, spec.max_depth, spec.background, batch_paths=3_000_000)
+        assert np.array_equal(film, small_queue) and st3["rays"] == st["rays"]
+        assert st3["traverse_launches"] > st["traverse_launches"]
+        whole, st4 = scene.render(cam, spp, spec.max_depth, spec.background, whole_paths=True)
+        assert np.array_equal(film, whole) and st4["rays"] == st["rays"] and st4["path_launches"] > 0
+        no_cull, _ = scene.render(cam, spp, spec.max_depth, spec.background, cull=False)
+        assert np.array_equal(film, no_cull)
+        a, sa = scene.render(cam, 100, spec.max_depth, spec.background, spp_begin=0)
+        b, sb = scene.render(cam, 100, spec.max_depth, spec.background, spp_begin=100)
+        assert sa["rays"] + sb["rays"] == st["rays"]
+        np.testing.assert_allclose(a + b, film, rtol=1e-12, atol=1e-12)
+        # a box lit from inside, seen through its open side: nothing is negative or NaN, and all but the margin
+        # around the opening received light
+        assert np.isfinite(film).all() and (film >= 0).all() and (film.sum(axis=2) > 0).mean() > 0.85
+    finally:
+        scene.close()
+
+
+def test_full_resolution_bvh_scene_properties():
+    """cornell_model at BASELINE's 800x800 (20 of its 2000 spp): the cull boxes and the queue size leave the film
+    bit-identical, and the run repeats exactly, on the kernel that hands rays to lanes in whatever order they free up."""
+    from raytracer_amd import HostBuilder, camera_new, scenes
+    spec = scenes.build("C4", HostBuilder(), width=800)
+    cam = camera_new(image_width=800, **spec.camera)
+    scene = spec.builder.commit(0)
+    try:
+        film, st = scene.render(cam, 20, spec.max_depth, spec.background)
+        again, _ = scene.render(cam, 20, spec.max_depth, spec.background)
+        assert np.array_equal(film, again)
+        no_cull, st_nc = scene.render(cam, 20, spec.max_depth, spec.background, cull=False, batch_paths=5_000_000)
+        assert np.array_equal(film, no_cull) and st_nc["rays"] == st["rays"]
+    finally:
+        scene.close()

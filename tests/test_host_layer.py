@@ -194,3 +194,76 @@ def test_commit_without_gpu_fails_loudly():
     hs = scenes.build("C3", HostBuilder(), **SMALL["C3"])
     with pytest.raises(RtError):
         hs.builder.commit(0)
+
+
+def test_extents_of_primitives_and_instances():
+    """Hittable::extent, the source of the cull boxes: exact geometric bounds, carried correctly through Translate and
+    RotateY (unlike the reference's RotateY bounding box, which is kept as the reference computes it)."""
+    b = HostBuilder()
+    m = b.mat_dielectric(1.5)
+    np.testing.assert_array_equal(b.extent(b.sphere((1.0, 2.0, 3.0), 0.5, m)), [0.5, 1.5, 1.5, 2.5, 2.5, 3.5])
+    np.testing.assert_array_equal(b.extent(b.quad((0.0, 1.0, 0.0), (2.0, 0.0, 0.0), (0.0, 0.0, -3.0), m)),
+                                  [0.0, 2.0, 1.0, 1.0, -3.0, 0.0])
+    np.testing.assert_array_equal(b.extent(b.triangle((0.0, 0.0, 0.0), (1.0, 2.0, 0.0), (0.0, -1.0, 5.0), m)),
+                                  [0.0, 1.0, -1.0, 2.0, 0.0, 5.0])
+    assert np.isinf(b.extent(b.y_cylinder((0.0, 0.0, 0.0), 1.0, m))).all()
+    box = b.slice(b.box((0.0, 0.0, 0.0), (165.0, 330.0, 165.0), m))
+    np.testing.assert_array_equal(b.extent(box), [0.0, 165.0, 0.0, 330.0, 0.0, 165.0])
+    inst = b.translate(b.rotate_y(box, 15.0), (265.0, 0.0, 295.0))
+    th = np.deg2rad(15.0)
+    xs, zs = [], []
+    for x in (0.0, 165.0):
+        for z in (0.0, 165.0):
+            xs.append(np.cos(th) * x + np.sin(th) * z + 265.0)
+            zs.append(-np.sin(th) * x + np.cos(th) * z + 295.0)
+    np.testing.assert_allclose(b.extent(inst), [min(xs), max(xs), 0.0, 330.0, min(zs), max(zs)], rtol=1e-14)
+    # a medium reports no bounds to what contains it: skipping it on the ray's interval would change its random draws
+    assert np.isinf(b.extent(b.constant_medium(inst, 0.01, b.tex_solid(0, 0, 0)))).all()
+    empty = b.slice(b.list_new())
+    e = b.extent(empty)
+    assert (e[0::2] > e[1::2]).all()
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_cull_boxes_bound_the_primitives_below_them(cfg):
+    """Every BVH / CULL entry's cull box contains all corner points of the primitives in its subtree (same instance
+    chain), with room to spare; a subtree holding a quadric has an infinite one."""
+    hs, _ = build_pair(cfg, **SMALL[cfg])
+    b = hs.builder
+    nodes, cull = b.flat("nodes"), b.flat("cull_boxes")
+    spheres, quads, tris = b.flat("spheres"), b.flat("quads"), b.flat("triangles")
+
+    def corners(kind, k):
+        if kind == "spheres":
+            c, r = spheres[k, :3], spheres[k, 3]
+            return np.array([c - r, c + r])
+        rec = (quads if kind == "quads" else tris)[k]
+        q, u, v = rec[4:7], rec[7:10], rec[10:13]
+        pts = [q, q + u, q + v]
+        if kind == "quads":
+            pts.append(q + u + v)
+        return np.array(pts)
+
+    open_ = []
+    checked = 0
+    for i, n in enumerate(nodes):
+        while open_ and open_[-1][0] == i:
+            open_.pop()
+        kind = _lib.NODE_KINDS[n.kind]
+        if kind in ("bvh", "cull"):
+            open_.append((n.skip, cull[n.first], n.chain))
+        elif kind == "medium":
+            open_.append((n.skip, None, n.chain))
+        else:
+            for skip, box, chain in open_:
+                if box is None or chain != n.chain:
+                    continue
+                if kind == "quadrics":
+                    assert np.isinf(box).all()
+                    continue
+                for k in range(n.first, n.first + n.count):
+                    p = corners(kind, k)
+                    assert (p >= box[0::2]).all() and (p <= box[1::2]).all(), (cfg, i, k)
+                    checked += 1
+    if cfg in ("C1", "C4", "C5"):
+        assert checked > 1000
