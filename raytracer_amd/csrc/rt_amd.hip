@@ -764,6 +764,10 @@ int rt_scene_commit(rt_scene* s, int device) {
         d.nodes = reinterpret_cast<const uint4*>(d_rec);
         s->nodes_nocull = reinterpret_cast<const uint4*>(d_rec_nc);
     }
+    {
+        std::vector<uint32_t> axis = quad_axis_flags(s->quads.data(), s->quad_mat.size());
+        UP(axis, quad_axis);
+    }
     UP(s->spheres, spheres); UP(s->quads, quads); UP(s->tris, tris);
     UP(s->quadrics, quadrics); UP(s->sphere_mat, sphere_mat); UP(s->sphere_id, sphere_id); UP(s->quad_mat, quad_mat);
     UP(s->quad_id, quad_id); UP(s->tri_mat, tri_mat); UP(s->tri_id, tri_id); UP(s->quadric_mat, quadric_mat);

@@ -133,6 +133,7 @@ struct DScene {
     const double* quadrics;  // 10 per quadric: p1(3) p2(3) p3(3) j
     const uint32_t* sphere_mat; const uint32_t* sphere_id;
     const uint32_t* quad_mat;   const uint32_t* quad_id;
+    const uint32_t* quad_axis;  // per quad: 1 + the axis its normal lies along when n and w are zero elsewhere, else 0
     const uint32_t* tri_mat;    const uint32_t* tri_id;
     const uint32_t* quadric_mat; const uint32_t* quadric_id;
     const rt_medium* media;
@@ -238,6 +239,7 @@ struct Tally {
 // `first` are then fetched once per wavefront with scalar loads instead of once per lane.
 #if defined(__HIP_DEVICE_COMPILE__)
 RT_HD uint32_t wave_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+RT_HD bool wave_all(bool p) { return __all(p) != 0; }
 RT_HD bool wave_uniform(uint32_t x, uint32_t& first) {
     first = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
     return __all(x == first) != 0;
@@ -246,6 +248,7 @@ RT_HD bool wave_uniform(uint32_t x, uint32_t& first) {
 inline bool& host_uniform_mode() { static bool m = true; return m; }  // lets CPU tests take either branch
 inline unsigned long long& host_fallback_count() { static unsigned long long n = 0; return n; }  // for the host tests
 RT_HD uint32_t wave_first(uint32_t x) { return x; }
+RT_HD bool wave_all(bool p) { return p; }
 RT_HD bool wave_uniform(uint32_t x, uint32_t& first) { first = x; return host_uniform_mode(); }
 #endif
 
@@ -316,6 +319,55 @@ RT_HD bool quad_t(const Planar& g, const Ray& r, double s, double e, double& t_o
     t_out = t;
     return true;
 }
+// Parallelogram::hit without branches, for runs that a whole wavefront works on together (one lane's early exit
+// saves the wavefront nothing there, and every branch costs exec-mask bookkeeping on the scalar unit): the same
+// operations in the same order, the tests folded into one predicate.  A t that fails the interval or parallel test
+// still flows through the remaining arithmetic; whatever it produces is discarded.
+RT_HD bool quad_flat_t(const Planar& g, const Ray& r, double s, double e, double& t_out) {
+    double den = dot(g.n, r.d);
+    double t = (g.d - dot(g.n, r.o)) / den;
+    bool ok = !(e < t) & !(t < s) & !(fabs(den) < 1e-8);
+    V3 ph = ray_at(r, t) - g.q;
+    double alpha = dot(g.w, cross(ph, g.v));
+    double beta = dot(g.w, cross(g.u, ph));
+    ok = ok & (0.0 <= alpha) & (alpha < 1.0) & (0.0 <= beta) & (beta < 1.0);
+    t_out = t;
+    return ok;
+}
+// The same for a quad whose normal lies along coordinate axis `ax` - 1 (n and w exactly zero in the other two
+// components, as for every side of create_box and of the Cornell box): the terms of the dot products that multiply
+// those zeros are left out.  For a tame ray (below) each of them is +-0, so den, t, alpha and beta come out with the
+// same values as in quad_t (at most the sign of a zero differs, which no comparison here sees).
+// (a: the normal's axis; b, c: the next two axes, cyclically.  Scalars by value and one call per axis, so that no
+// field is ever picked by a run-time index.)
+RT_HD bool quad_axis_core(double na, double wa, double gd, double oa, double da, double ob, double db, double qb,
+                          double ub, double vb, double oc, double dc, double qc, double uc, double vc, double s,
+                          double e, double& t_out) {
+    double den = na * da;
+    double t = (gd - na * oa) / den;
+    bool ok = !(e < t) & !(t < s) & !(fabs(den) < 1e-8);
+    double phb = (ob + t * db) - qb, phc = (oc + t * dc) - qc;
+    double alpha = wa * (phb * vc - phc * vb);  // w . cross(ph, v)
+    double beta = wa * (ub * phc - uc * phb);   // w . cross(u, ph)
+    ok = ok & (0.0 <= alpha) & (alpha < 1.0) & (0.0 <= beta) & (beta < 1.0);
+    t_out = t;
+    return ok;
+}
+RT_HD bool quad_axis_t(const Planar& g, uint32_t ax, const Ray& r, double s, double e, double& t_out) {
+    if (ax == 1u)
+        return quad_axis_core(g.n.x, g.w.x, g.d, r.o.x, r.d.x, r.o.y, r.d.y, g.q.y, g.u.y, g.v.y, r.o.z, r.d.z, g.q.z,
+                              g.u.z, g.v.z, s, e, t_out);
+    if (ax == 2u)
+        return quad_axis_core(g.n.y, g.w.y, g.d, r.o.y, r.d.y, r.o.z, r.d.z, g.q.z, g.u.z, g.v.z, r.o.x, r.d.x, g.q.x,
+                              g.u.x, g.v.x, s, e, t_out);
+    return quad_axis_core(g.n.z, g.w.z, g.d, r.o.z, r.d.z, r.o.x, r.d.x, g.q.x, g.u.x, g.v.x, r.o.y, r.d.y, g.q.y,
+                          g.u.y, g.v.y, s, e, t_out);
+}
+// The shortcut above needs products with zero to be zero: no infinity or NaN in the ray, and magnitudes that
+// cannot overflow on the way (record values are checked the same way where quad_axis is filled in).
+RT_HD bool ray_is_tame(const Ray& r) {
+    return fabs(r.o.x) + fabs(r.o.y) + fabs(r.o.z) + fabs(r.d.x) + fabs(r.d.y) + fabs(r.d.z) < 1e100;
+}
 // Triangle::hit, triangle.rs:123-144: parallel check first, half-open interval, strict barycentric test.
 RT_HD bool tri_t(const Planar& g, const Ray& r, double s, double e, double& t_out) {
     double den = dot(g.n, r.d);
@@ -372,7 +424,9 @@ RT_HD bool quadric_t(const double2* q, const Ray& r, double s, double e, double&
 
 // One run of `count` primitives of one type, in list order, against the interval (s, e): HittableSlice::hit
 // (hittable_list.rs:88-102) with closest_so_far kept in e.
-template <bool COUNT>
+// UNIFORM: every lane of the wavefront is on this same run (its records are wavefront-uniform); per-quad choices
+// such as the axis-aligned shortcut are then uniform branches.
+template <bool COUNT, bool UNIFORM = false>
 RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t count, uint32_t chain, const Ray& cur,
                      double s, double e, Best& best, Tally& tally) {
     const uint32_t last = first + count;
@@ -388,12 +442,29 @@ RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t co
         }
     } else if (kind == RT_NODE_QUADS) {
         const double2* base = reinterpret_cast<const double2*>(S.quads);
-        for (uint32_t k = first; k < last; ++k) {
-            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
-            double t;
-            if (quad_t(load_planar(base + 8u * k), cur, s, e, t)) {
-                best.t = t; best.ref = make_ref(RT_NODE_QUADS, k); best.chain = chain;
-                e = t;  // t <= e already: a later quad at the same t replaces an earlier one
+        if (UNIFORM) {
+            // a wavefront whose rays are not all tame (never, in a render) takes the general form for all of them
+            const bool tame = wave_all(ray_is_tame(cur));
+            for (uint32_t k = first; k < last; ++k) {
+                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+                double t;
+                const Planar g = load_planar(base + 8u * k);
+                const uint32_t ax = S.quad_axis[k];
+                const bool hit = (ax != 0u && tame) ? quad_axis_t(g, ax, cur, s, e, t) : quad_flat_t(g, cur, s, e, t);
+                // t <= e already: a later quad at the same t replaces an earlier one
+                best.t = hit ? t : best.t;
+                best.ref = hit ? make_ref(RT_NODE_QUADS, k) : best.ref;
+                best.chain = hit ? chain : best.chain;
+                e = hit ? t : e;
+            }
+        } else {
+            for (uint32_t k = first; k < last; ++k) {
+                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+                double t;
+                if (quad_t(load_planar(base + 8u * k), cur, s, e, t)) {
+                    best.t = t; best.ref = make_ref(RT_NODE_QUADS, k); best.chain = chain;
+                    e = t;  // t <= e already: a later quad at the same t replaces an earlier one
+                }
             }
         }
     } else if (kind == RT_NODE_SPHERES) {
@@ -491,6 +562,18 @@ RT_HD void two_min_add(TwoMin& w, double t) {
         w.dirty = true;
     }
 }
+// The same update written without branches, applied only where `on` holds (for the wavefront-uniform scan).
+RT_HD void two_min_add_flat(TwoMin& w, double t, bool on) {
+    const bool lower = on & (t < w.m1);
+    const bool old_beyond = w.m1 >= t + 0.0001;
+    const bool beyond = t >= w.m1 + 0.0001;
+    const bool upper = on & !(t < w.m1);
+    w.lost = w.lost | (lower & w.dirty);
+    w.dirty = w.dirty | (lower & !old_beyond) | (upper & !beyond);
+    const double m2_upper = fmin(w.m2, t);
+    w.m2 = lower ? (old_beyond ? w.m1 : w.m2) : ((upper & beyond) ? m2_upper : w.m2);
+    w.m1 = lower ? t : w.m1;
+}
 template <bool COUNT, bool LOCKSTEP, class Src>
 RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const Node& n, Ray& cur, uint32_t& cur_chain,
                              Tally& tally, double& t1, double& t2, bool& lost) {
@@ -524,9 +607,21 @@ RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const 
         } else {
             const bool is_tri = r.kind == RT_NODE_TRIANGLES;
             const double2* base = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads);
-            for (uint32_t k = r.first; k < last; ++k) {
-                double t;
-                if (planar_t(load_planar(base + 8u * k), is_tri, cur, -RT_INF, RT_INF, t)) two_min_add(w, t);
+            if (LOCKSTEP && !is_tri) {
+                const bool tame = wave_all(ray_is_tame(cur));
+                for (uint32_t k = r.first; k < last; ++k) {
+                    double t;
+                    const Planar g = load_planar(base + 8u * k);
+                    const uint32_t ax = S.quad_axis[k];
+                    const bool hit = (ax != 0u && tame) ? quad_axis_t(g, ax, cur, -RT_INF, RT_INF, t)
+                                                        : quad_flat_t(g, cur, -RT_INF, RT_INF, t);
+                    two_min_add_flat(w, t, hit);
+                }
+            } else {
+                for (uint32_t k = r.first; k < last; ++k) {
+                    double t;
+                    if (planar_t(load_planar(base + 8u * k), is_tri, cur, -RT_INF, RT_INF, t)) two_min_add(w, t);
+                }
             }
             if (COUNT) { tests += r.count; bytes += 136u * r.count; }
         }
@@ -635,7 +730,7 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
                 // all lanes stand on the same run (top-level lists, shared leaves): the entry and its records are
                 // addressed by a wavefront-uniform index and fetched with scalar loads
                 const Node nu = load_node(S, i0);
-                run_prims<COUNT>(S, nu.kind, nu.first, nu.count, nu.chain, cur, s, e, best, tally);
+                run_prims<COUNT, true>(S, nu.kind, nu.first, nu.count, nu.chain, cur, s, e, best, tally);
             } else {
                 run_prims<COUNT>(S, n.kind, n.first, n.count, n.chain, cur, s, e, best, tally);
             }

@@ -12,6 +12,7 @@
 // pointing at the next entry, because a ray whose interval is already empty fails even an infinite box.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -52,6 +53,25 @@ inline std::vector<uint32_t> build_records(const rt_node* nodes, size_t n_nodes,
         std::memcpy(r, &n, sizeof(rt_node));
     }
     return rec;
+}
+
+// Per quad (16 f64: n d q u v w): 1 + the coordinate axis its normal lies along when n and w are exactly zero in the
+// other two components and every value is of a magnitude that cannot overflow in the intersection arithmetic; else 0.
+inline std::vector<uint32_t> quad_axis_flags(const double* quads, size_t n_quads) {
+    std::vector<uint32_t> out(n_quads, 0u);
+    for (size_t k = 0; k < n_quads; ++k) {
+        const double* q = quads + 16 * k;
+        bool tame = true;
+        for (int j = 0; j < 16; ++j) tame = tame && std::fabs(q[j]) < 1e100;  // false for NaN too
+        if (!tame) continue;
+        const double* nrm = q;
+        const double* w = q + 13;
+        for (int a = 0; a < 3; ++a) {
+            const int b = (a + 1) % 3, c = (a + 2) % 3;
+            if (nrm[a] != 0.0 && nrm[b] == 0.0 && nrm[c] == 0.0 && w[b] == 0.0 && w[c] == 0.0) out[k] = 1u + (uint32_t)a;
+        }
+    }
+    return out;
 }
 
 }  // namespace rt

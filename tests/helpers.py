@@ -40,10 +40,10 @@ def cameras(spec):
 
 
 class sim_scene(C.Structure):
-    _fields_ = [(n, C.c_void_p) if n != "n_nodes" else (n, C.c_uint64) for n in
+    _fields_ = [(n, C.c_void_p) if n not in ("n_nodes", "n_quads") else (n, C.c_uint64) for n in
                 ["nodes", "n_nodes", "boxes", "spheres", "quads", "tris", "quadrics", "sphere_mat", "sphere_id",
                  "quad_mat", "quad_id", "tri_mat", "tri_id", "quadric_mat", "quadric_id", "media", "ops", "chains",
-                 "mats", "texs", "texels", "image_desc", "perlin_vec", "perlin_perm", "cull_boxes"]]
+                 "mats", "texs", "texels", "image_desc", "perlin_vec", "perlin_perm", "cull_boxes", "n_quads"]]
 
 
 _SIM = None
@@ -78,6 +78,8 @@ class HostSim:
             setattr(self.sc, name, p)
             if name == "nodes":
                 self.sc.n_nodes = n
+            if name == "quads":
+                self.sc.n_quads = n
         self.L = _sim_lib()
 
     def intersect(self, o, d, tmin, tmax, rng3=None, seed=42):

@@ -19,9 +19,10 @@ struct sim_scene {  // host pointers to the arrays of a flattened scene
     const rt_texture* texs; const uint8_t* texels; const uint32_t* image_desc; const double* perlin_vec;
     const uint32_t* perlin_perm;
     const double* cull_boxes;  // one per box, or null
+    uint64_t n_quads;
 };
 
-static std::vector<uint32_t> g_records;
+static std::vector<uint32_t> g_records, g_quad_axis;
 static int use_cull = 1;      // 0: every cull box switched off, as under RT_FLAG_NO_CULL
 static int use_one_pass = 1;  // 0: media always take their two boundary hits in two passes
 static DScene to_dscene(const sim_scene* s) {
@@ -33,6 +34,9 @@ static DScene to_dscene(const sim_scene* s) {
     d.quadric_mat = s->quadric_mat; d.quadric_id = s->quadric_id; d.media = s->media; d.ops = s->ops; d.chains = s->chains;
     d.mats = s->mats; d.texs = s->texs; d.texels = s->texels; d.image_desc = s->image_desc; d.perlin_vec = s->perlin_vec;
     d.perlin_perm = s->perlin_perm;
+    g_quad_axis = quad_axis_flags(s->quads, (size_t)s->n_quads);
+    g_quad_axis.push_back(0u);
+    d.quad_axis = g_quad_axis.data();
     return d;
 }
 
