@@ -225,6 +225,16 @@ int rt_render(const rt_scene* s, const rt_camera* cam, const rt_render_opts* opt
 int rt_render_device(const rt_scene* s, const rt_camera* cam, const rt_render_opts* opts, void* film_rgb_device,
                      rt_stats* stats);
 
+/* The same on several GPUs from ONE process: scenes[r] is the same scene committed to device r (rt_scene_commit
+ * with different devices; the same device may appear more than once).  The samples [spp_begin, spp_begin +
+ * spp_count) are split into n contiguous shards (the remainder goes to the low ranks, unlike camera.rs:324, which
+ * drops it), every shard is rendered on its device by a host thread of its own, and the shard films are brought to
+ * scenes[0]'s device (peer copies) and added in rank order; film_rgb is a host buffer.  stats (nullable) holds
+ * sums over the shards, times being the slowest shard's.  The multi-process equivalent -- one process per GPU and
+ * an all-reduce of rt_render_device's film -- needs no call of its own. */
+int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* opts,
+                    double* film_rgb, rt_stats* stats);
+
 /* Per-sample radiance of chosen (pixel, sample) pairs: get_ray + ray_color for each (camera.rs:258-264).
  * radiance3 has 3 f64 per pair; nrays (nullable) the number of world.hit calls of each path. */
 int rt_trace_samples(const rt_scene* s, const rt_camera* cam, const rt_render_opts* opts, uint64_t n,

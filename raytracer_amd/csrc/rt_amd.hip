@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_core.h"
@@ -402,6 +403,10 @@ __global__ void k_film_accumulate(const double* lum_r, const double* lum_g, cons
         r = r + lum_r[k]; g = g + lum_g[k]; b = b + lum_b[k];
     }
     film[3u * pix] = r; film[3u * pix + 1u] = g; film[3u * pix + 2u] = b;
+}
+__global__ void k_film_add(double* dst, const double* src, size_t n) {  // one shard's film onto another's
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = dst[i] + src[i];
 }
 __global__ void k_fill(double* p, size_t n, double v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1139,6 +1144,89 @@ int rt_render(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o,
     if (rc == RT_OK && hipMemcpy(film_rgb, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(RT_ERR_DEVICE, "film copy back failed");
     (void)hipFree(d_film);
+    return rc;
+}
+
+int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* o,
+                    double* film_rgb, rt_stats* stats) {
+    if (!scenes || n < 1 || n > 64) return fail(RT_ERR_INVALID, "bad scene list");
+    for (int r = 0; r < n; ++r) {
+        if (!scenes[r]) return fail(RT_ERR_INVALID, "null scene");
+        if (!scenes[r]->committed) return fail(RT_ERR_STATE, "scene not committed");
+        for (int q = 0; q < r; ++q)
+            if (scenes[q] == scenes[r]) return fail(RT_ERR_INVALID, "the same scene handle twice (a handle is not re-entrant)");
+    }
+    int rc = check_render_args(scenes[0], cam, o);
+    if (rc) return rc;
+    if (!film_rgb) return fail(RT_ERR_INVALID, "null film");
+    const size_t npix = (size_t)cam->width * cam->height, bytes = 3 * npix * sizeof(double);
+    struct Shard { void* film = nullptr; rt_stats st; int rc = RT_OK; std::string err; };
+    std::vector<Shard> sh((size_t)n);
+    std::vector<std::thread> workers;
+    const uint32_t base = o->spp_count / (uint32_t)n, extra = o->spp_count % (uint32_t)n;
+    for (int r = 0; r < n; ++r) {
+        workers.emplace_back([&, r]() {
+            Shard& me = sh[(size_t)r];
+            std::memset(&me.st, 0, sizeof me.st);
+            rt_render_opts mine = *o;
+            mine.spp_count = base + ((uint32_t)r < extra ? 1u : 0u);
+            mine.spp_begin = o->spp_begin + (uint32_t)r * base + std::min<uint32_t>((uint32_t)r, extra);
+            hipError_t e = hipSetDevice(scenes[r]->device);
+            if (e == hipSuccess) e = hipMalloc(&me.film, bytes);
+            if (e != hipSuccess) { me.rc = RT_ERR_DEVICE; me.err = hipGetErrorString(e); return; }
+            me.rc = rt_render_device(scenes[r], cam, &mine, me.film, &me.st);
+            if (me.rc != RT_OK) me.err = rt_last_error();  // the error text is per thread
+        });
+    }
+    for (auto& w : workers) w.join();
+    rc = RT_OK;
+    for (int r = 0; r < n && rc == RT_OK; ++r)
+        if (sh[(size_t)r].rc != RT_OK) rc = fail(sh[(size_t)r].rc, "shard %d: %s", r, sh[(size_t)r].err.c_str());
+    // gather on the first device and add in rank order
+    const int dev0 = scenes[0]->device;
+    void* tmp = nullptr;
+    std::vector<double> staging;
+    if (rc == RT_OK && hipSetDevice(dev0) != hipSuccess) rc = fail(RT_ERR_DEVICE, "cannot select device %d", dev0);
+    if (rc == RT_OK && n > 1 && hipMalloc(&tmp, bytes) != hipSuccess) rc = fail(RT_ERR_DEVICE, "out of device memory");
+    for (int r = 1; r < n && rc == RT_OK; ++r) {
+        const int dev = scenes[r]->device;
+        hipError_t e = dev == dev0 ? hipMemcpy(tmp, sh[(size_t)r].film, bytes, hipMemcpyDeviceToDevice)
+                                   : hipMemcpyPeer(tmp, dev0, sh[(size_t)r].film, dev, bytes);
+        if (e != hipSuccess) {  // no peer path between the two devices: through the host
+            (void)hipGetLastError();
+            staging.resize(3 * npix);
+            e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipMemcpy(staging.data(), sh[(size_t)r].film, bytes, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipSetDevice(dev0);
+            if (e == hipSuccess) e = hipMemcpy(tmp, staging.data(), bytes, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_film_add, dim3((uint32_t)((3 * npix + 255) / 256)), dim3(256), 0, 0, (double*)sh[0].film,
+                               (const double*)tmp, 3 * npix);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "gathering shard %d: %s", r, hipGetErrorString(e));
+    }
+    if (rc == RT_OK && hipMemcpy(film_rgb, sh[0].film, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(RT_ERR_DEVICE, "film copy back failed");
+    if (tmp) (void)hipFree(tmp);
+    for (int r = 0; r < n; ++r)
+        if (sh[(size_t)r].film) { (void)hipSetDevice(scenes[r]->device); (void)hipFree(sh[(size_t)r].film); }
+    if (rc == RT_OK && stats) {
+        rt_stats t;
+        std::memset(&t, 0, sizeof t);
+        for (int r = 0; r < n; ++r) {
+            const rt_stats& a = sh[(size_t)r].st;
+            t.paths += a.paths; t.rays += a.rays; t.node_tests += a.node_tests; t.prim_tests += a.prim_tests;
+            t.cull_tests += a.cull_tests; t.prim_bytes += a.prim_bytes;
+            t.ms_total = std::max(t.ms_total, a.ms_total); t.ms_traverse = std::max(t.ms_traverse, a.ms_traverse);
+            t.ms_shade = std::max(t.ms_shade, a.ms_shade); t.ms_paths = std::max(t.ms_paths, a.ms_paths);
+            t.traverse_launches += a.traverse_launches; t.path_launches += a.path_launches;
+            t.bounces = std::max(t.bounces, a.bounces); t.lockstep = a.lockstep;
+        }
+        *stats = t;
+    }
     return rc;
 }
 

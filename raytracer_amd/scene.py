@@ -104,6 +104,19 @@ class Scene:
         return rgb
 
 
+def render_multi(scenes, cam, spp, max_depth, background, seed=42, spp_begin=0, batch_paths=0):
+    """rt_render_multi: one process, scenes[r] committed to GPU r; the samples are split over them and the shard films
+    added in rank order.  Returns (film of radiance sums (H, W, 3), stats summed over the shards)."""
+    film = np.zeros((cam.height, cam.width, 3))
+    st = rt_stats()
+    o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, 0)
+    handles = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+    rc = _lib.amd().rt_render_multi(handles, len(scenes), C.byref(cam), C.byref(o), film.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise RtError(f"rt_amd error {rc}: {_lib.last_error()}")
+    return film, _stats_dict(st)
+
+
 def debug_arith(a, b, device=0):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)

@@ -263,3 +263,28 @@ def test_full_resolution_bvh_scene_properties():
         assert np.array_equal(film, no_cull) and st_nc["rays"] == st["rays"]
     finally:
         scene.close()
+
+
+def test_render_multi_splits_samples_and_adds_shards_in_rank_order():
+    """rt_render_multi on a one-GPU box: the same scene committed three times to device 0 stands in for three GPUs.
+    The result must be, bit for bit, the rank-ordered sum of the three shard renders (7 samples -> 3 + 2 + 2)."""
+    from raytracer_amd import HostBuilder, camera_new, scenes
+    from raytracer_amd.scene import render_multi
+    spec = scenes.build("C5", HostBuilder(), **SMALL["C5"])
+    cam = camera_new(image_width=spec.width, **spec.camera)
+    devs = [spec.builder.commit(0) for _ in range(3)]
+    try:
+        film, st = render_multi(devs, cam, 7, spec.max_depth, spec.background, spp_begin=2)
+        parts = [devs[0].render(cam, n, spec.max_depth, spec.background, spp_begin=b) for b, n in ((2, 3), (5, 2), (7, 2))]
+        want = (parts[0][0] + parts[1][0]) + parts[2][0]
+        assert np.array_equal(film, want)
+        assert st["rays"] == sum(p[1]["rays"] for p in parts) and st["paths"] == 7 * cam.width * cam.height
+        whole, _ = devs[0].render(cam, 7, spec.max_depth, spec.background, spp_begin=2)
+        np.testing.assert_allclose(film, whole, rtol=1e-12, atol=1e-12)
+        one, _ = render_multi(devs[:1], cam, 7, spec.max_depth, spec.background, spp_begin=2)
+        assert np.array_equal(one, whole)
+        with pytest.raises(Exception):
+            render_multi([devs[0], devs[0]], cam, 4, spec.max_depth, spec.background)
+    finally:
+        for d in devs:
+            d.close()
