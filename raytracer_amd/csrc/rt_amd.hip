@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, T
 #define RT_CHUNK 256u
 #define RT_STEP_THRESHOLD 20
 #define RT_FETCH_THRESHOLD 16
-template <bool COUNT>
+template <bool COUNT, bool MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
         // Likewise a step runs only when enough lanes are waiting for it, or when it is what most lanes want.
         const bool do_node = n_node >= RT_STEP_THRESHOLD || n_node >= n_run;
         const bool do_run = n_run >= RT_STEP_THRESHOLD || n_run > n_node;
-        if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT>(S, src, ln, L, rng, tally);
+        if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT, MEDIA>(S, src, ln, L, rng, tally);
         if (do_run && ln.state == RT_ST_RUN) lane_prim_step<COUNT>(S, ln, tally);
     }
     if (COUNT) tally_flush(tally, tallies);
@@ -805,8 +805,12 @@ int rt_scene_commit(rt_scene* s, int device) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false>, TRAV_BLOCK,
-                                                             (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
+        if (s->media.empty())
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false, false>, TRAV_BLOCK,
+                                                                 (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
+        else
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false, true>, TRAV_BLOCK,
+                                                                 (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
         if (per_cu < 1) per_cu = 1;
         s->persist_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false>, TRAV_BLOCK,
@@ -860,8 +864,11 @@ static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocu
     } else {
         HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
         const uint32_t grid = std::min(waves, s->persist_waves);
-        if (count) hipLaunchKernelGGL(k_traverse_persistent<true>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_count + 4, s->d_tallies);
-        else hipLaunchKernelGGL(k_traverse_persistent<false>, dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_count + 4, s->d_tallies);
+        const bool media = !s->media.empty();
+#define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_count + 4, s->d_tallies)
+        if (count) { if (media) PERSIST(true, true); else PERSIST(true, false); }
+        else { if (media) PERSIST(false, true); else PERSIST(false, false); }
+#undef PERSIST
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;

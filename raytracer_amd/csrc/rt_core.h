@@ -777,7 +777,9 @@ RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const 
     lv_set(L, 0u, tmin, tmax);
 }
 // One entry of the tree for a lane in RT_ST_NODE.
-template <bool COUNT, class Src>
+// MEDIA = false is for scenes without a ConstantMedium: the medium code, its random draw and its logarithm then
+// cost the kernel no registers.
+template <bool COUNT, bool MEDIA = true, class Src>
 RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Levels& L, RngPos& rng, Tally& tally) {
     if (ln.i >= S.n_nodes) { ln.state = RT_ST_DONE; return; }
     // The whole 128-byte record at once, whatever its kind: the boxes and the leaf's run sit in the same cache line
@@ -826,7 +828,7 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         ln.i = slab3(b0, b1, b2, ln.cur, cs, ce) ? ln.i + 1u : n.skip;
         return;
     }
-    if (n.kind == RT_NODE_MEDIUM) {
+    if (MEDIA && n.kind == RT_NODE_MEDIUM) {
         // ConstantMedium::hit, constant_medium.rs:46-93 (same steps as in walk())
         if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
         const rt_medium m = S.media[n.first];
