@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, T
 #define RT_CHUNK 256u
 #define RT_STEP_THRESHOLD 20
 #define RT_FETCH_THRESHOLD 16
+#define RT_MEDIUM_THRESHOLD 18
 template <bool COUNT, bool MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
@@ -158,9 +159,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
         const unsigned long long mask = __ballot(need);
         int n_node = __popcll(__ballot(ln.state == RT_ST_NODE));
         int n_run = __popcll(__ballot(ln.state == RT_ST_RUN));
+        int n_med = MEDIA ? __popcll(__ballot(ln.state == RT_ST_MEDIUM)) : 0;
         // hand out rays only when enough lanes are free (or nobody has work): the hand-out code costs the whole
         // wavefront its instructions however few lanes it serves
-        if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run == 0)) {
+        if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run + n_med == 0)) {
             if (need && idx != 0xFFFFFFFFu) {
                 a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
                 a.q.ctr[idx] = rng.ctr;
@@ -195,11 +197,16 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
             n_node = __popcll(__ballot(ln.state == RT_ST_NODE));
             n_run = __popcll(__ballot(ln.state == RT_ST_RUN));
         }
-        // Likewise a step runs only when enough lanes are waiting for it, or when it is what most lanes want.
+        // Likewise a step runs only when enough lanes are waiting for it, or when it is what most lanes want; a
+        // medium, the most expensive step by far, when enough lanes have gathered or nothing else can move.
         const bool do_node = n_node >= RT_STEP_THRESHOLD || n_node >= n_run;
         const bool do_run = n_run >= RT_STEP_THRESHOLD || n_run > n_node;
+        const bool do_med = MEDIA && (n_med >= RT_MEDIUM_THRESHOLD || (n_med > 0 && n_node + n_run == 0));
         if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT, MEDIA>(S, src, ln, L, rng, tally);
         if (do_run && ln.state == RT_ST_RUN) lane_prim_step<COUNT>(S, ln, tally);
+        if (MEDIA) {
+            if (do_med && ln.state == RT_ST_MEDIUM) lane_medium_step<COUNT>(S, src, ln, L, rng, tally);
+        }
     }
     if (COUNT) tally_flush(tally, tallies);
 }

@@ -756,6 +756,7 @@ RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax
 #define RT_ST_NODE 0u
 #define RT_ST_RUN 1u
 #define RT_ST_DONE 2u
+#define RT_ST_MEDIUM 3u  // standing on a MEDIUM entry, waiting for lane_medium_step
 struct Lane {
     Ray cur;
     uint32_t cur_chain;
@@ -829,32 +830,44 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         return;
     }
     if (MEDIA && n.kind == RT_NODE_MEDIUM) {
-        // ConstantMedium::hit, constant_medium.rs:46-93 (same steps as in walk())
-        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
-        const rt_medium m = S.media[n.first];
-        const double ray_length = sqrt(ln.cur.a);
-        double t1 = 0.0, t2 = 0.0;
-        if (boundary_hits<COUNT, false>(S, src, ln.i, n, L, rng, ln.cur, ln.cur_chain, tally, t1, t2)) {
-            t1 = fmax(t1, s);
-            t2 = fmin(t2, e);
-            t1 = fmax(t1, 0.0);
-            double inside = (t2 - t1) * ray_length;
-            double x = rng_draw_at(rng.k0, rng.k1, rng.pixel, rng.sample, rng.ctr) * (1.0 - 0.0) + 0.0;
-            rng.ctr++;
-            double hit_distance = m.neg_inv_density * log(x);
-            if (!(hit_distance > inside)) {
-                ln.best.t = t1 + hit_distance / ray_length;
-                ln.best.ref = make_ref(RT_NODE_MEDIUM, n.first);
-                ln.best.chain = n.chain;
-            }
-        }
-        ln.i = n.skip;
+        // A medium costs several times what any other entry does (two boundary hits, a random draw, a logarithm),
+        // and the wavefront pays for it whenever a single lane gets here: the lane waits in RT_ST_MEDIUM until the
+        // caller has collected enough of them for one lane_medium_step.
+        ln.state = RT_ST_MEDIUM;
         return;
     }
     if (n.count == 0u) { ln.i = ln.i + 1u; return; }
     ln.kind = n.kind; ln.k = n.first; ln.kend = n.first + n.count;
     ln.s = s; ln.e = e;
     ln.state = RT_ST_RUN;
+}
+// The MEDIUM entry a lane in RT_ST_MEDIUM stands on: ConstantMedium::hit, constant_medium.rs:46-93 (same steps as in
+// walk()).
+template <bool COUNT, class Src>
+RT_HD void lane_medium_step(const DScene& S, const Src& src, Lane& ln, const Levels& L, RngPos& rng, Tally& tally) {
+    const Node n = load_node(S, ln.i);
+    const double2 iv = lv_get(L, n.level);
+    const double s = iv.x, e = fmin(iv.y, ln.best.t);
+    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
+    const rt_medium m = S.media[n.first];
+    const double ray_length = sqrt(ln.cur.a);  // lane_node_step has put the ray into the entry's chain
+    double t1 = 0.0, t2 = 0.0;
+    if (boundary_hits<COUNT, false>(S, src, ln.i, n, L, rng, ln.cur, ln.cur_chain, tally, t1, t2)) {
+        t1 = fmax(t1, s);
+        t2 = fmin(t2, e);
+        t1 = fmax(t1, 0.0);
+        double inside = (t2 - t1) * ray_length;
+        double x = rng_draw_at(rng.k0, rng.k1, rng.pixel, rng.sample, rng.ctr) * (1.0 - 0.0) + 0.0;
+        rng.ctr++;
+        double hit_distance = m.neg_inv_density * log(x);
+        if (!(hit_distance > inside)) {
+            ln.best.t = t1 + hit_distance / ray_length;
+            ln.best.ref = make_ref(RT_NODE_MEDIUM, n.first);
+            ln.best.chain = n.chain;
+        }
+    }
+    ln.i = n.skip;
+    ln.state = RT_ST_NODE;
 }
 // The next primitive(s) of the run in progress for a lane in RT_ST_RUN: two per step where the run has two left, so
 // that both records are in flight together and the step's fixed costs are shared.
