@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, T
 #define RT_STEP_THRESHOLD 20
 #define RT_FETCH_THRESHOLD 16
 #define RT_MEDIUM_THRESHOLD 18
+#define RT_CHAIN_THRESHOLD 12
 template <bool COUNT, bool MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
@@ -160,9 +161,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
         int n_node = __popcll(__ballot(ln.state == RT_ST_NODE));
         int n_run = __popcll(__ballot(ln.state == RT_ST_RUN));
         int n_med = MEDIA ? __popcll(__ballot(ln.state == RT_ST_MEDIUM)) : 0;
+        const int n_chain = __popcll(__ballot(ln.state == RT_ST_CHAIN));
         // hand out rays only when enough lanes are free (or nobody has work): the hand-out code costs the whole
         // wavefront its instructions however few lanes it serves
-        if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run + n_med == 0)) {
+        if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run + n_med + n_chain == 0)) {
             if (need && idx != 0xFFFFFFFFu) {
                 a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
                 a.q.ctr[idx] = rng.ctr;
@@ -202,6 +204,8 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
         const bool do_node = n_node >= RT_STEP_THRESHOLD || n_node >= n_run;
         const bool do_run = n_run >= RT_STEP_THRESHOLD || n_run > n_node;
         const bool do_med = MEDIA && (n_med >= RT_MEDIUM_THRESHOLD || (n_med > 0 && n_node + n_run == 0));
+        const bool do_chain = n_chain >= RT_CHAIN_THRESHOLD || (n_chain > 0 && n_node + n_run == 0);
+        if (do_chain && ln.state == RT_ST_CHAIN) lane_chain_step(S, src, ln);
         if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT, MEDIA>(S, src, ln, L, rng, tally);
         if (do_run && ln.state == RT_ST_RUN) lane_prim_step<COUNT>(S, ln, tally);
         if (MEDIA) {

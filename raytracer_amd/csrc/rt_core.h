@@ -757,6 +757,7 @@ RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax
 #define RT_ST_RUN 1u
 #define RT_ST_DONE 2u
 #define RT_ST_MEDIUM 3u  // standing on a MEDIUM entry, waiting for lane_medium_step
+#define RT_ST_CHAIN 4u   // standing on an entry of another instance chain, waiting for lane_chain_step
 struct Lane {
     Ray cur;
     uint32_t cur_chain;
@@ -769,6 +770,7 @@ struct Lane {
 template <class Src>
 RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const Levels& L) {
     ln.cur = src.world();
+    ray_need_inv(ln.cur);
     ln.cur_chain = 0;
     ln.i = 0;
     ln.k = ln.kend = 0; ln.kind = 0;
@@ -798,10 +800,14 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
     Node n;
     n.kind = raw.x & 0xFFu; n.level = raw.x >> 8 & 0xFFu; n.chain = raw.x >> 16;
     n.skip = raw.y; n.first = raw.z; n.count = raw.w;
-    if (n.chain != ln.cur_chain) { ln.cur = ray_in_chain(S, src.world(), n.chain); ln.cur_chain = n.chain; }
+    if (n.chain != ln.cur_chain) {
+        // re-reading the world ray, running it through the chain's transforms and taking the reciprocal of its new
+        // direction is a detour the whole wavefront would take for one lane: collected like the media
+        ln.state = RT_ST_CHAIN;
+        return;
+    }
     const double s = iv0.x, e = fmin(iv0.y, ln.best.t);
     if (n.kind == RT_NODE_BVH) {
-        ray_need_inv(ln.cur);
         double bs = s, be = e;
         if (COUNT) { tally.node_tests++; tally.cull_tests++; }
         {
@@ -823,7 +829,6 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         return;
     }
     if (n.kind == RT_NODE_CULL) {
-        ray_need_inv(ln.cur);
         if (COUNT) tally.cull_tests++;
         double cs = s, ce = e;
         ln.i = slab3(b0, b1, b2, ln.cur, cs, ce) ? ln.i + 1u : n.skip;
@@ -840,6 +845,17 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
     ln.kind = n.kind; ln.k = n.first; ln.kend = n.first + n.count;
     ln.s = s; ln.e = e;
     ln.state = RT_ST_RUN;
+}
+// Takes a lane in RT_ST_CHAIN into the ray space of the entry it stands on (Translate::hit / RotateY::hit,
+// hittable/mod.rs:78-91,118-135), reciprocal direction included (Ray::new, ray.rs:14-19): the state machine keeps
+// it ready at all times, so that no box test has to stop for three divisions.
+template <class Src>
+RT_HD void lane_chain_step(const DScene& S, const Src& src, Lane& ln) {
+    const Node n = load_node(S, ln.i);
+    ln.cur = ray_in_chain(S, src.world(), n.chain);
+    ray_need_inv(ln.cur);
+    ln.cur_chain = n.chain;
+    ln.state = RT_ST_NODE;
 }
 // The MEDIUM entry a lane in RT_ST_MEDIUM stands on: ConstantMedium::hit, constant_medium.rs:46-93 (same steps as in
 // walk()).
@@ -866,6 +882,7 @@ RT_HD void lane_medium_step(const DScene& S, const Src& src, Lane& ln, const Lev
             ln.best.chain = n.chain;
         }
     }
+    ray_need_inv(ln.cur);  // the boundary may have left the lane in another chain, whose next entry may be a box
     ln.i = n.skip;
     ln.state = RT_ST_NODE;
 }

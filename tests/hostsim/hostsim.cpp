@@ -69,6 +69,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
                 if (ln.state == RT_ST_NODE) lane_node_step<true>(S, src, ln, L, rng, tally);
                 if (ln.state == RT_ST_RUN) lane_prim_step<true>(S, ln, tally);
                 if (ln.state == RT_ST_MEDIUM) lane_medium_step<true>(S, src, ln, L, rng, tally);
+                if (ln.state == RT_ST_CHAIN) lane_chain_step(S, src, ln);
             }
             b = ln.best;
         } else if (mode == 1) {

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import helpers
+from raytracer_amd import _lib
 from helpers import SMALL, HostSim, assert_hits_equal, build_pair, cameras, path_rays
 
 CONFIGS = ["C1", "C2", "C3", "C4", "C5"]
@@ -267,3 +268,46 @@ def test_media_boundary_hits_through_edges_corners_and_tangents():
         assert_hits_equal(got_nc, want, exact=True, what=f"one pass without cull boxes, mode {mode}")
         assert got_nc["counters"]["prim_tests"] == want["counters"]["prim_tests"]
         assert 0 < fallbacks < 0.2 * n, fallbacks   # the undecidable cases occur here, and stay the exception
+
+
+def test_state_machine_after_a_medium_whose_boundary_changes_chain():
+    """A medium whose boundary sits in an instance chain, followed by a BVH in that same chain: the walk comes out of
+    the medium in the boundary's ray space and goes straight into box tests there."""
+    from oracle import oracle as orc
+    from raytracer_amd import HostBuilder
+    from raytracer_amd.philox import SceneRng
+
+    def make(b):
+        rng = SceneRng(5)
+        m = b.mat_lambertian(b.tex_solid(0.5, 0.5, 0.5))
+        off = (3.0, -1.0, 2.0)
+        balls = b.list_new()
+        for _ in range(60):
+            b.list_add(balls, b.sphere(rng.vector(-6.0, 6.0), rng.range(0.2, 0.9), m))
+        world = b.list_new()
+        b.list_add(world, b.constant_medium(b.translate(b.sphere((0.0, 0.0, 0.0), 4.0, m), off), 0.4, b.tex_solid(1, 1, 1)))
+        b.list_add(world, b.translate(b.bvh(balls), off))
+        b.set_world(b.slice(world))
+
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    make(hb)
+    make(ob)
+    nodes = hb.flat("nodes")
+    kinds = [_lib.NODE_KINDS[n.kind] for n in nodes]
+    med, bvh = kinds.index("medium"), kinds.index("bvh")
+    assert nodes[med].chain == 0 and nodes[med + 1].chain == nodes[bvh].chain != 0
+    sim = HostSim(hb)
+    rs = np.random.RandomState(8)
+    n = 3000
+    o = rs.uniform(-20, 20, (n, 3))
+    d = (np.array([3.0, -1.0, 2.0]) - o) + rs.uniform(-5, 5, (n, 3))
+    rng3 = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.uint32)
+    want = ob.intersect(o, d, 0.001, np.inf, rng3)
+    L = helpers._sim_lib()
+    for mode in (0, 2):
+        L.sim_set_walk_mode(mode)
+        try:
+            got = sim.intersect(o, d, 0.001, np.inf, rng3)
+        finally:
+            L.sim_set_walk_mode(0)
+        assert_hits_equal(got, want, exact=True, what=f"mode {mode}")
