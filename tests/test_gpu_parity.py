@@ -288,3 +288,39 @@ def test_render_multi_splits_samples_and_adds_shards_in_rank_order():
     finally:
         for d in devs:
             d.close()
+
+
+def test_edge_cases_empty_inputs_and_limits(gpu_scenes):
+    """What the reference does at the edges: an empty world shows the background (camera.rs:364-366 on a miss);
+    depth 0 is black (camera.rs:350-352); zero samples leave the fold's start value -0.0 (point3/mod.rs:96-109);
+    empty ray batches and sample lists are no-ops; bad arguments are errors, not crashes."""
+    from raytracer_amd import HostBuilder, RtError, camera_new
+    b = HostBuilder()
+    b.set_world(b.slice(b.list_new()))
+    scene = b.commit(0)
+    cam = camera_new(image_width=16, aspect_ratio=1.0, vfov=40.0, look_from=(0, 0, -5), look_at=(0, 0, 0), view_up=(0, 1, 0),
+                     defocus_angle=0.0, focus_distance=1.0)
+    try:
+        film, st = scene.render(cam, 3, 5, (0.25, 0.5, 1.0))
+        assert np.array_equal(film, np.broadcast_to(np.array([0.75, 1.5, 3.0]), film.shape))
+        assert st["rays"] == st["paths"] == 3 * cam.width * cam.height
+        r = scene.intersect(np.zeros((4, 3)), np.ones((4, 3)), 0.001, np.inf)
+        assert not r["hit"].any() and (r["prim"] == 0xFFFFFFFF).all()
+    finally:
+        scene.close()
+    hs, os_, scene = gpu_scenes("C2")
+    hc, oc = cameras(hs)
+    film, st = scene.render(hc, 2, 0, hs.background)
+    assert np.array_equal(film, np.zeros_like(film)) and not np.signbit(film).any() and st["rays"] == 0
+    film, st = scene.render(hc, 0, 5, hs.background)
+    assert (film == 0).all() and np.signbit(film).all() and st["paths"] == 0
+    r = scene.intersect(np.zeros((0, 3)), np.zeros((0, 3)), 0.001, np.inf)
+    assert r["hit"].shape == (0,)
+    rad, nr = scene.trace_samples(hc, np.zeros(0, np.uint32), np.zeros(0, np.uint32), 5, hs.background)
+    assert rad.shape == (0, 3)
+    with pytest.raises(RtError):
+        scene.trace_samples(hc, np.array([hc.width * hc.height], np.uint32), np.array([0], np.uint32), 5, hs.background)
+    # a ray that starts exactly on a wall and one parallel to it: same answers as the oracle
+    o = np.array([[0.0, 100.0, 100.0], [278.0, 278.0, -800.0], [555.0, 10.0, 10.0]])
+    d = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    assert_hits_equal(scene.intersect(o, d, 0.0, np.inf), os_.builder.intersect(o, d, 0.0, np.inf), exact=True, what="walls")
