@@ -89,6 +89,7 @@ struct TravArgs {
     uint32_t n;
     const double* tmin;     // nullable
     const double* tmax;     // nullable
+    uint32_t chunk;         // rays a wavefront of the persistent kernel takes per hand-out
 };
 __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, RngPos& rng, double& tmin, double& tmax) {
     rng.k0 = (uint32_t)a.seed; rng.k1 = (uint32_t)(a.seed >> 32);
@@ -174,10 +175,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
                 if (pool_next == pool_end) {
                     const int leader = __ffsll((long long)mask) - 1;
                     uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(work, RT_CHUNK);
+                    if ((int)lane == leader) base = atomicAdd(work, a.chunk);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                     pool_next = base < a.n ? base : a.n;
-                    pool_end = (base + RT_CHUNK) < a.n ? (base + RT_CHUNK) : a.n;
+                    pool_end = (base + a.chunk) < a.n ? (base + a.chunk) : a.n;
                     if (base >= a.n) { pool_end = pool_next; exhausted = true; }
                 }
                 if (!exhausted) {
@@ -875,8 +876,12 @@ static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocu
     } else {
         HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
         const uint32_t grid = std::min(waves, s->persist_waves);
+        // RT_CHUNK rays per hand-out when there is plenty of work; fewer (down to one wavefront's worth) when the
+        // launch is small, so that the rays spread over the whole device instead of queueing up behind a few waves
+        TravArgs sized = a;
+        sized.chunk = std::max(64u, std::min(RT_CHUNK, (a.n / std::max(1u, s->persist_waves) + 63u) / 64u * 64u));
         const bool media = !s->media.empty();
-#define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_count + 4, s->d_tallies)
+#define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, sized, s->d_count + 4, s->d_tallies)
         if (count) { if (media) PERSIST(true, true); else PERSIST(true, false); }
         else { if (media) PERSIST(false, true); else PERSIST(false, false); }
 #undef PERSIST
