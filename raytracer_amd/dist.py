@@ -33,6 +33,10 @@ def render_sharded(render_range, film, spp_total, group=None):
         film.zero_()
     if world > 1:
         dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group)
+        if film.is_cuda:
+            # the renderer works on a stream of its own, ordered against this one only through the host: the sum
+            # must have landed before the caller renders into the same film again (or reads it through the C ABI)
+            torch.cuda.current_stream(film.device).synchronize()
     return begin, count
 
 
