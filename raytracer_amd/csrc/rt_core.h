@@ -104,10 +104,23 @@ RT_HD double rng_next01(Rng& r) {
 }
 RT_HD double rng_range(Rng& r, double lo, double hi) { return rng_next01(r) * (hi - lo) + lo; }
 RT_HD V3 random_unit_vector(Rng& r) {  // point3/mod.rs:229-250
+    // Draws ctr, ctr + 1, ctr + 2 of every trial lie in blocks ctr >> 1 and (ctr >> 1) + 1: both are generated for
+    // all lanes alike and the three values picked by the parity of ctr.  Going through rng_next01 instead, lanes of
+    // either parity would need their next block at different draws and a wavefront would run the generator three
+    // times per trial, each time for half of its lanes.
     for (;;) {
-        double x = rng_range(r, -1.0, 1.0);
-        double y = rng_range(r, -1.0, 1.0);
-        double z = rng_range(r, -1.0, 1.0);
+        const uint32_t c = r.ctr, b0 = c >> 1;
+        uint32_t w0[4] = {r.pixel, r.sample, b0, 0u}, w1[4] = {r.pixel, r.sample, b0 + 1u, 0u};
+        philox4x32_10(w0, r.k0, r.k1);
+        philox4x32_10(w1, r.k0, r.k1);
+        const uint64_t lo0 = ((uint64_t)w0[1] << 32) | w0[0], hi0 = ((uint64_t)w0[3] << 32) | w0[2];
+        const uint64_t lo1 = ((uint64_t)w1[1] << 32) | w1[0], hi1 = ((uint64_t)w1[3] << 32) | w1[2];
+        const bool odd = (c & 1u) != 0u;
+        double x = unit_interval(odd ? hi0 : lo0) * (1.0 - -1.0) + -1.0;
+        double y = unit_interval(odd ? lo1 : hi0) * (1.0 - -1.0) + -1.0;
+        double z = unit_interval(odd ? hi1 : lo1) * (1.0 - -1.0) + -1.0;
+        r.ctr = c + 3u;
+        r.blk = 0xFFFFFFFFu;
         V3 p = mk(x, y, z);
         if (len2(p) < 1.0) return unit(p);
     }
