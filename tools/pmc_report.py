@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+"""Per-kernel digest of a summary.json written by tools/pmc_summary.py (development aid).
+usage: tools/pmc_report.py <summary.json>"""
 import json, sys
 d = json.load(open(sys.argv[1]))
 for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["total_ms"]):

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""One render of a benchmark configuration at its default size, printing rt_stats (development aid).
+usage: tools/render_stats.py <config> <spp> [count]      (`count` also collects the work counters)"""
 import sys; sys.path.insert(0,'.')
 from raytracer_amd import HostBuilder, camera_new, scenes
 cfg, spp = sys.argv[1], int(sys.argv[2])
