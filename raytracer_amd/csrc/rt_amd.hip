@@ -342,7 +342,8 @@ __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8
 // Material::emitted / scatter on the closest hit, throughput update, termination, and compaction of the
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
-__global__ void __launch_bounds__(SHADE_BLOCK, 4) k_shade(DScene S, uint64_t seed, uint32_t n, Queue q, HitBuf hb,
+template <bool PLAIN>
+__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, uint64_t seed, uint32_t n, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
                                                        uint32_t iter, uint32_t max_depth) {
@@ -364,11 +365,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK, 4) k_shade(DScene S, uint64_t see
             smp = q.smp[idx];
             Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
             Best b; b.t = hb.t[idx]; b.ref = ref; b.chain = hb.chain[idx];
-            Rec rec = finalize<false>(S, w, b);
+            Rec rec = finalize<false, PLAIN>(S, w, b);
             Rng rng = rng_make(seed, pix, smp, q.ctr[idx]);
             V3 att, emit;
             const rt_material m = S.mats[rec.mat];
-            if (!scatter(S, m, w.d, rec, rng, nd, att, emit)) {
+            if (!scatter<PLAIN>(S, m, w.d, rec, rng, nd, att, emit)) {
                 lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
             } else if (iter - born + 1u == max_depth) {
                 // the scattered ray would be traced with depth 0: ray_color returns black (camera.rs:350-352)
@@ -498,6 +499,7 @@ struct rt_scene {
     int device = -1;
     uint32_t levels = 0;  // interval slots per lane the walk needs
     bool has_bvh = false; // selects the traverse kernel: lockstep (no BVH entries) or persistent
+    bool plain = false;   // only Lambertian / DiffuseLight / Isotropic over SolidColor: selects the lean shade kernel
     uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
     uint32_t path_waves = 0;     // the same for the whole-path kernel
     std::vector<void*> allocs;
@@ -739,6 +741,11 @@ static int validate(rt_scene* s) {
     s->levels = max_level + 1u;
     s->has_bvh = false;
     for (uint32_t i = 0; i < nn; ++i) s->has_bvh |= s->nodes[i].kind == RT_NODE_BVH;
+    s->plain = true;
+    for (const rt_material& m : s->mats) {
+        const bool kind_ok = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+        s->plain = s->plain && kind_ok && s->texs[m.texture].kind == RT_TEX_SOLID;
+    }
     if (s->levels > RT_MAX_LEVELS) return fail(RT_ERR_LIMIT, "scene needs %u levels, limit %d", s->levels, RT_MAX_LEVELS);
     return RT_OK;
 }
@@ -1109,9 +1116,11 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.n = n;
             if ((rc = launch_traverse(s, ta, count, (o->flags & RT_FLAG_NO_CULL) != 0))) return rc;
             HIP_TRY(hipEventRecord(s->ev[2], sm));
-            hipLaunchKernelGGL(k_shade, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, s->d, o->seed, n,
-                               qin, s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0],
-                               o->background[1], o->background[2], iter, o->max_depth);
+#define SHADE_ARGS s->d, o->seed, n, qin, s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
+                   o->background[1], o->background[2], iter, o->max_depth
+            if (s->plain) hipLaunchKernelGGL(k_shade<true>, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+            else hipLaunchKernelGGL(k_shade<false>, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+#undef SHADE_ARGS
             HIP_TRY(hipEventRecord(s->ev[3], sm));
             HIP_TRY(hipMemcpyAsync(s->h_count, s->d_count, 4, hipMemcpyDeviceToHost, sm));
             HIP_TRY(hipStreamSynchronize(sm));

@@ -984,7 +984,9 @@ RT_HD bool mat_reads_uv(const DScene& S, uint32_t mat) {
     const uint32_t k = S.texs[m.texture].kind;
     return k == RT_TEX_IMAGE || k == RT_TEX_CHECKER;
 }
-template <bool FULL>
+// PLAIN = true is for scenes whose materials are all Lambertian, DiffuseLight or Isotropic over SolidColor textures
+// (checked where the scene is committed): nothing reads (u, v) then.
+template <bool FULL, bool PLAIN = false>
 RT_HD Rec finalize(const DScene& S, const Ray& wray, const Best& b) {
     Rec r;
     Ray ray = ray_in_chain(S, wray, b.chain);
@@ -997,7 +999,7 @@ RT_HD Rec finalize(const DScene& S, const Ray& wray, const Best& b) {
             V3 outward = (r.p - mk(sp[0], sp[1], sp[2])) / sp[3];
             face_normal(r, ray.d, outward);
             r.mat = S.sphere_mat[k]; r.prim_id = S.sphere_id[k];
-            if (FULL || mat_reads_uv(S, r.mat)) sphere_uv(outward, r.u, r.v);
+            if (FULL || (!PLAIN && mat_reads_uv(S, r.mat))) sphere_uv(outward, r.u, r.v);
             break;
         }
         case RT_NODE_QUADS:
@@ -1005,7 +1007,7 @@ RT_HD Rec finalize(const DScene& S, const Ray& wray, const Best& b) {
             const double* q = (kind == RT_NODE_QUADS ? S.quads : S.tris) + 16u * k;
             if (kind == RT_NODE_QUADS) { r.mat = S.quad_mat[k]; r.prim_id = S.quad_id[k]; }
             else { r.mat = S.tri_mat[k]; r.prim_id = S.tri_id[k]; }
-            if (FULL || mat_reads_uv(S, r.mat)) {
+            if (FULL || (!PLAIN && mat_reads_uv(S, r.mat))) {
                 V3 ph = r.p - ld3(q + 4);
                 r.u = dot(ld3(q + 13), cross(ph, ld3(q + 10)));
                 r.v = dot(ld3(q + 13), cross(ld3(q + 7), ph));
@@ -1115,9 +1117,26 @@ RT_HD double reflectance(double cosine, double ri) {  // material.rs:161-166
     double r0s = r0 * r0;
     return r0s + (1.0 - r0s) * pow(1.0 - cosine, 5.0);
 }
+template <bool PLAIN = false>
 RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& rec, Rng& rng, V3& out_d, V3& att,
                    V3& emit) {
     emit = mk(0, 0, 0);
+    if (PLAIN) {
+        // the three materials of a plain scene over solid colours: no checker / image / perlin code, no metal, no
+        // dielectric (whose pow alone would set the kernel's register count)
+        const rt_texture t = S.texs[m.texture];
+        const V3 colour = mk(t.color[0], t.color[1], t.color[2]);
+        if (m.kind == RT_MAT_DIFFUSE_LIGHT) { emit = colour; return false; }
+        const V3 ruv = random_unit_vector(rng);
+        if (m.kind == RT_MAT_LAMBERTIAN) {
+            V3 temp = rec.n + ruv;
+            out_d = near_zero(temp) ? rec.n : temp;
+        } else {
+            out_d = ruv;
+        }
+        att = colour;
+        return true;
+    }
     // What several materials share is evaluated once, ahead of the switch, so that a wavefront with a mix of
     // materials runs the rejection loop and the texture code once instead of once per material.  The random unit
     // vector is the first (and only) thing Lambertian, Metal and Isotropic draw, so the stream is unchanged.
