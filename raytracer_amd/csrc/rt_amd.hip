@@ -110,7 +110,7 @@ __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long lo
 
 // world.hit(ray, 0.001..inf) for every queued path (camera.rs:363), for trees WITHOUT BVH entries: one lane per
 // ray, all lanes visit the same entries in the same order, scene data comes through scalar loads.
-template <bool COUNT>
+template <bool COUNT, bool MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, T
         trav_ray_setup(a, idx, rng, tmin, tmax);
         RaySoA src;
         src.ox = a.q.ox; src.oy = a.q.oy; src.oz = a.q.oz; src.dx = a.q.dx; src.dy = a.q.dy; src.dz = a.q.dz; src.idx = idx;
-        Best b = closest_hit<COUNT, true>(S, src, tmin, tmax, L, rng, tally);
+        Best b = closest_hit<COUNT, true, MEDIA>(S, src, tmin, tmax, L, rng, tally);
         a.hb.t[idx] = b.t; a.hb.ref[idx] = b.ref; a.hb.chain[idx] = b.chain;
         a.q.ctr[idx] = rng.ctr;
     }
@@ -878,8 +878,11 @@ static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocu
     if (nocull) d.nodes = s->nodes_nocull;
     const uint32_t waves = (a.n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     if (!s->has_bvh) {
-        if (count) hipLaunchKernelGGL(k_traverse_lockstep<true>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies);
-        else hipLaunchKernelGGL(k_traverse_lockstep<false>, dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies);
+        const bool media = !s->media.empty();
+#define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
+        if (count) { if (media) LOCKSTEP(true, true); else LOCKSTEP(true, false); }
+        else { if (media) LOCKSTEP(false, true); else LOCKSTEP(false, false); }
+#undef LOCKSTEP
     } else {
         HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
         const uint32_t grid = std::min(waves, s->persist_waves);

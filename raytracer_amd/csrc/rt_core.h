@@ -758,14 +758,14 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
 }
 
 // world.hit(ray, tmin..tmax) (camera.rs:363): returns the closest hit as (t, ref, chain).
-template <bool COUNT, bool LOCKSTEP, class Src>
+template <bool COUNT, bool LOCKSTEP, bool MEDIA = true, class Src>
 RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax, const Levels& L, RngPos& rng,
                        Tally& tally) {
     Best best; best.t = RT_INF; best.ref = RT_NO_HIT; best.chain = 0;
     lv_set(L, 0u, tmin, tmax);
     Ray cur = src.world();
     uint32_t cur_chain = 0;
-    walk<true, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
+    walk<MEDIA, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
     return best;
 }
 
