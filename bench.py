@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--whole-paths", action="store_true", help="RT_FLAG_WHOLE_PATHS: one kernel per batch (BVH-free scenes)")
+    ap.add_argument("--queues", action="store_true", help="RT_FLAG_QUEUES: the queue-based schedule whatever the scene")
     args = ap.parse_args()
 
     import torch
@@ -83,12 +84,14 @@ def main():
 
     from raytracer_amd.dist import render_sharded
 
+    schedule = True if args.whole_paths else (False if args.queues else None)
+
     def step():
         st = {}
 
         def render_range(begin, count):
             st.update(scene.render_into(cam, count, spec.max_depth, spec.background, film.data_ptr(), spp_begin=begin,
-                                        batch_paths=args.batch_paths, whole_paths=args.whole_paths))
+                                        batch_paths=args.batch_paths, whole_paths=schedule))
 
         render_sharded(render_range, film, spp * world)  # rank r renders samples [r*spp, (r+1)*spp), then RCCL all-reduce
         return st

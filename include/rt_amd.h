@@ -143,8 +143,11 @@ typedef struct rt_render_opts {
 #define RT_FLAG_NO_CULL 2u  /* ignore the conservative cull boxes: do exactly the tests the reference does */
 #define RT_FLAG_WHOLE_PATHS 4u /* scenes without BVH entries only (ignored otherwise): trace whole paths in one
                                   kernel, path state in registers, instead of the queue-based schedule (one traverse
-                                  and one shade launch per bounce over all paths in flight); the film is the same
-                                  either way */
+                                  and one shade launch per bounce over all paths in flight).  Without either flag the
+                                  library picks: whole paths where that kernel is lean (no BVH entries, no media,
+                                  only Lambertian / DiffuseLight / Isotropic over solid colours), queues otherwise.
+                                  The film is the same either way */
+#define RT_FLAG_QUEUES 8u      /* always the queue-based schedule */
 
 typedef struct rt_stats {
     uint64_t paths;      /* camera samples traced */

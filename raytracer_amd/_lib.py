@@ -60,6 +60,7 @@ class rt_stats(C.Structure):
 RT_FLAG_COUNTERS = 1
 RT_FLAG_NO_CULL = 2
 RT_FLAG_WHOLE_PATHS = 4
+RT_FLAG_QUEUES = 8
 RT_NO_HIT = 0xFFFFFFFF
 NODE_KINDS = {0: "bvh", 1: "medium", 2: "spheres", 3: "quads", 4: "triangles", 5: "quadrics", 6: "cull"}
 

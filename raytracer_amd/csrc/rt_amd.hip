@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
 // registers: no queues, no hit buffer, no compaction.  The only traffic is one radiance per path into lum[] at the
 // path's batch index j = s_local * npix + pixel, which k_film_accumulate then adds up in sample order.
 // counters[0] += rays traced, counters[1] = max(deepest bounce).
-template <bool COUNT>
+template <bool COUNT, bool MEDIA, bool PLAIN>
 __global__ void __launch_bounds__(TRAV_BLOCK, 2) k_paths_lockstep(DScene S, rt_camera cam, uint64_t seed, uint32_t npix,
                                                                    uint32_t sample0, uint32_t npaths, uint32_t max_depth,
                                                                    double bgr, double bgg, double bgb, double* lum_r,
@@ -278,17 +278,17 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 2) k_paths_lockstep(DScene S, rt_c
             Ray w = src.world();
             rays++;
             RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32); rp.pixel = pix; rp.sample = smp; rp.ctr = ctr;
-            Best b = closest_hit<COUNT, true>(S, src, 0.001, RT_INF, L, rp, tally);
+            Best b = closest_hit<COUNT, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
             V3 lum = mk(0, 0, 0);
             if (b.ref == RT_NO_HIT) {
                 lum = beta * mk(bgr, bgg, bgb);
                 alive = false;
             } else {
-                Rec rec = finalize<false>(S, w, b);
+                Rec rec = finalize<false, PLAIN>(S, w, b);
                 Rng rng = rng_make(seed, pix, smp, rp.ctr);
                 V3 nd, att, emit;
                 const rt_material m = S.mats[rec.mat];
-                if (!scatter(S, m, w.d, rec, rng, nd, att, emit)) {
+                if (!scatter<PLAIN>(S, m, w.d, rec, rng, nd, att, emit)) {
                     lum = beta * emit;
                     alive = false;
                 } else if (depth + 1u == max_depth) {
@@ -832,8 +832,14 @@ int rt_scene_commit(rt_scene* s, int device) {
                                                                  (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
         if (per_cu < 1) per_cu = 1;
         s->persist_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false>, TRAV_BLOCK,
-                                                             (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
+        {
+            const size_t lds = (size_t)s->levels * TRAV_BLOCK * sizeof(double2);
+            const bool media = !s->media.empty();
+            if (media && s->plain) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, true, true>, TRAV_BLOCK, lds));
+            else if (media) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, true, false>, TRAV_BLOCK, lds));
+            else if (s->plain) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, false, true>, TRAV_BLOCK, lds));
+            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, false, false>, TRAV_BLOCK, lds));
+        }
         if (per_cu < 1) per_cu = 1;
         s->path_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }
@@ -1034,7 +1040,8 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                        (o->max_depth == 0 && o->spp_count > 0) ? 0.0 : -0.0);
     if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 64, sm));
 
-    const bool fused = !s->has_bvh && (o->flags & RT_FLAG_WHOLE_PATHS) != 0;
+    const bool lean_paths = s->plain && s->media.empty();
+    const bool fused = !s->has_bvh && !(o->flags & RT_FLAG_QUEUES) && ((o->flags & RT_FLAG_WHOLE_PATHS) != 0 || lean_paths);
     if (o->max_depth > 0 && o->spp_count > 0 && fused) {
         // whole paths in one kernel, batch after batch; a batch is as many samples of every pixel as fit the budget
         const uint64_t budget = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (32ull << 20), npix);
@@ -1059,8 +1066,12 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             if (e != hipSuccess) { rc2 = fail(RT_ERR_DEVICE, "path batch set-up: %s", hipGetErrorString(e)); break; }
 #define PATH_ARGS d, *cam, o->seed, npix, o->spp_begin + b * spb, nb, o->max_depth, o->background[0], o->background[1], \
                   o->background[2], s->lum_r, s->lum_g, s->lum_b, s->d_count + 4, (unsigned long long*)(s->d_count + 8), s->d_tallies
-            if (count) hipLaunchKernelGGL(k_paths_lockstep<true>, dim3(grid), dim3(TRAV_BLOCK), levels_lds(s, TRAV_BLOCK), sm, PATH_ARGS);
-            else hipLaunchKernelGGL(k_paths_lockstep<false>, dim3(grid), dim3(TRAV_BLOCK), levels_lds(s, TRAV_BLOCK), sm, PATH_ARGS);
+#define PATHS(C, M, P) hipLaunchKernelGGL((k_paths_lockstep<C, M, P>), dim3(grid), dim3(TRAV_BLOCK), levels_lds(s, TRAV_BLOCK), sm, PATH_ARGS)
+            const bool media = !s->media.empty();
+            if (count) PATHS(true, true, false);  // counting passes need no speed: one instantiation serves all scenes
+            else if (media) { if (s->plain) PATHS(false, true, true); else PATHS(false, true, false); }
+            else { if (s->plain) PATHS(false, false, true); else PATHS(false, false, false); }
+#undef PATHS
 #undef PATH_ARGS
             e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(evs[2 * b + 1], sm);

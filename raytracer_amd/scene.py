@@ -17,8 +17,9 @@ def _opts(spp_begin, spp_count, max_depth, seed, background, batch_paths=0, flag
 
 
 def _flags(counters, cull, whole_paths):
+    """whole_paths: None = the library's choice, True / False = force one kernel per batch / the queue schedule."""
     return ((_lib.RT_FLAG_COUNTERS if counters else 0) | (0 if cull else _lib.RT_FLAG_NO_CULL) |
-            (_lib.RT_FLAG_WHOLE_PATHS if whole_paths else 0))
+            (0 if whole_paths is None else (_lib.RT_FLAG_WHOLE_PATHS if whole_paths else _lib.RT_FLAG_QUEUES)))
 
 
 def _stats_dict(st):
@@ -66,11 +67,11 @@ class Scene:
         return out
 
     def render(self, cam, spp, max_depth, background, seed=42, spp_begin=0, batch_paths=0, counters=False,
-               cull=True, whole_paths=False):
+               cull=True, whole_paths=None):
         """Camera::render: returns (film of radiance SUMS, shape (H, W, 3), stats dict).  cull=False switches the
         cull boxes off: the same film from exactly the box and primitive tests the reference performs.
-        whole_paths=True traces whole paths in one kernel instead of the queue-based schedule (scenes without BVH
-        entries only)."""
+        whole_paths=True traces whole paths in one kernel (scenes without BVH entries only), False forces the
+        queue-based schedule, None leaves the choice to the library."""
         film = np.zeros((cam.height, cam.width, 3))
         st = rt_stats()
         o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths))
@@ -78,7 +79,7 @@ class Scene:
         return film, _stats_dict(st)
 
     def render_into(self, cam, spp, max_depth, background, film_device_ptr, seed=42, spp_begin=0, batch_paths=0,
-                    counters=False, cull=True, whole_paths=False):
+                    counters=False, cull=True, whole_paths=None):
         """Same, into a caller-owned device buffer of H*W*3 f64 (e.g. a torch tensor's data_ptr())."""
         st = rt_stats()
         o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths))

@@ -99,7 +99,7 @@ def test_film_equals_sum_of_samples(gpu_scenes, cfg, schedule):
     hc, _ = cameras(hs)
     spp = 3
     film, stats = scene.render(hc, spp, hs.max_depth, hs.background, spp_begin=5, batch_paths=2 * hc.width * hc.height,
-                               whole_paths=schedule == "whole-paths")
+                               whole_paths=schedule == "whole-paths")  # forced either way
     assert (stats["path_launches"] > 0) == (schedule == "whole-paths" and cfg in ("C2", "C3"))
     assert (stats["traverse_launches"] > 0) != (stats["path_launches"] > 0)
     npix = hc.width * hc.height
@@ -235,6 +235,8 @@ def test_full_size_headline_workload_properties():
         assert st3["traverse_launches"] > st["traverse_launches"]
         whole, st4 = scene.render(cam, spp, spec.max_depth, spec.background, whole_paths=True)
         assert np.array_equal(film, whole) and st4["rays"] == st["rays"] and st4["path_launches"] > 0
+        queues, st5 = scene.render(cam, spp, spec.max_depth, spec.background, whole_paths=False)
+        assert np.array_equal(film, queues) and st5["traverse_launches"] > 0
         no_cull, _ = scene.render(cam, spp, spec.max_depth, spec.background, cull=False)
         assert np.array_equal(film, no_cull)
         a, sa = scene.render(cam, 100, spec.max_depth, spec.background, spp_begin=0)
