@@ -110,7 +110,7 @@ __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long lo
 
 // world.hit(ray, 0.001..inf) for every queued path (camera.rs:363), for trees WITHOUT BVH entries: one lane per
 // ray, all lanes visit the same entries in the same order, scene data comes through scalar loads.
-template <bool COUNT, bool MEDIA>
+template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, T
 #define RT_FETCH_THRESHOLD 16
 #define RT_MEDIUM_THRESHOLD 18
 #define RT_CHAIN_THRESHOLD 12
-template <bool COUNT, bool MEDIA>
+template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
         const unsigned long long mask = __ballot(need);
         int n_node = __popcll(__ballot(ln.state == RT_ST_NODE));
         int n_run = __popcll(__ballot(ln.state == RT_ST_RUN));
-        int n_med = MEDIA ? __popcll(__ballot(ln.state == RT_ST_MEDIUM)) : 0;
+        int n_med = MEDIA != RT_MEDIA_NONE ? __popcll(__ballot(ln.state == RT_ST_MEDIUM)) : 0;
         const int n_chain = __popcll(__ballot(ln.state == RT_ST_CHAIN));
         // hand out rays only when enough lanes are free (or nobody has work): the hand-out code costs the whole
         // wavefront its instructions however few lanes it serves
@@ -204,13 +204,13 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
         // medium, the most expensive step by far, when enough lanes have gathered or nothing else can move.
         const bool do_node = n_node >= RT_STEP_THRESHOLD || n_node >= n_run;
         const bool do_run = n_run >= RT_STEP_THRESHOLD || n_run > n_node;
-        const bool do_med = MEDIA && (n_med >= RT_MEDIUM_THRESHOLD || (n_med > 0 && n_node + n_run == 0));
+        const bool do_med = MEDIA != RT_MEDIA_NONE && (n_med >= RT_MEDIUM_THRESHOLD || (n_med > 0 && n_node + n_run == 0));
         const bool do_chain = n_chain >= RT_CHAIN_THRESHOLD || (n_chain > 0 && n_node + n_run == 0);
         if (do_chain && ln.state == RT_ST_CHAIN) lane_chain_step(S, src, ln);
         if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT, MEDIA>(S, src, ln, L, rng, tally);
         if (do_run && ln.state == RT_ST_RUN) lane_prim_step<COUNT>(S, ln, tally);
-        if (MEDIA) {
-            if (do_med && ln.state == RT_ST_MEDIUM) lane_medium_step<COUNT>(S, src, ln, L, rng, tally);
+        if (MEDIA != RT_MEDIA_NONE) {
+            if (do_med && ln.state == RT_ST_MEDIUM) lane_medium_step<COUNT, MEDIA == RT_MEDIA_ANY>(S, src, ln, L, rng, tally);
         }
     }
     if (COUNT) tally_flush(tally, tallies);
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S,
 // registers: no queues, no hit buffer, no compaction.  The only traffic is one radiance per path into lum[] at the
 // path's batch index j = s_local * npix + pixel, which k_film_accumulate then adds up in sample order.
 // counters[0] += rays traced, counters[1] = max(deepest bounce).
-template <bool COUNT, bool MEDIA, bool PLAIN>
+template <bool COUNT, int MEDIA, bool PLAIN>
 __global__ void __launch_bounds__(TRAV_BLOCK, 2) k_paths_lockstep(DScene S, rt_camera cam, uint64_t seed, uint32_t npix,
                                                                    uint32_t sample0, uint32_t npaths, uint32_t max_depth,
                                                                    double bgr, double bgg, double bgb, double* lum_r,
@@ -499,6 +499,7 @@ struct rt_scene {
     int device = -1;
     uint32_t levels = 0;  // interval slots per lane the walk needs
     bool has_bvh = false; // selects the traverse kernel: lockstep (no BVH entries) or persistent
+    int media_mode = RT_MEDIA_NONE;  // RT_MEDIA_FLAT when every medium's boundary is plain primitives, else RT_MEDIA_ANY
     bool plain = false;   // only Lambertian / DiffuseLight / Isotropic over SolidColor: selects the lean shade kernel
     uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
     uint32_t path_waves = 0;     // the same for the whole-path kernel
@@ -781,6 +782,13 @@ int rt_scene_commit(rt_scene* s, int device) {
     {
         const double* cb = s->cull_boxes.empty() ? nullptr : s->cull_boxes.data();
         std::vector<uint32_t> rec = build_records(s->nodes.data(), s->nodes.size(), s->boxes.data(), cb, true, true);
+        s->media_mode = RT_MEDIA_NONE;
+        for (size_t i = 0; i < s->nodes.size(); ++i) {
+            if (s->nodes[i].kind != RT_NODE_MEDIUM) continue;
+            const bool flat = rec[32 * i + 3] == 1u;  // the record's count field
+            if (!flat) s->media_mode = RT_MEDIA_ANY;
+            else if (s->media_mode == RT_MEDIA_NONE) s->media_mode = RT_MEDIA_FLAT;
+        }
         std::vector<uint32_t> rec_nc = build_records(s->nodes.data(), s->nodes.size(), s->boxes.data(), cb, false, true);
         const uint32_t *d_rec = nullptr, *d_rec_nc = nullptr;
         if ((rc = upload(s, rec, &d_rec))) return rc;
@@ -824,21 +832,22 @@ int rt_scene_commit(rt_scene* s, int device) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         int per_cu = 0;
-        if (s->media.empty())
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false, false>, TRAV_BLOCK,
-                                                                 (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
+        const size_t lds_bytes = (size_t)s->levels * TRAV_BLOCK * sizeof(double2);
+        if (s->media_mode == RT_MEDIA_NONE)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false, RT_MEDIA_NONE>, TRAV_BLOCK, lds_bytes));
+        else if (s->media_mode == RT_MEDIA_FLAT)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false, RT_MEDIA_FLAT>, TRAV_BLOCK, lds_bytes));
         else
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false, true>, TRAV_BLOCK,
-                                                                 (size_t)s->levels * TRAV_BLOCK * sizeof(double2)));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_persistent<false, RT_MEDIA_ANY>, TRAV_BLOCK, lds_bytes));
         if (per_cu < 1) per_cu = 1;
         s->persist_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
         {
             const size_t lds = (size_t)s->levels * TRAV_BLOCK * sizeof(double2);
-            const bool media = !s->media.empty();
-            if (media && s->plain) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, true, true>, TRAV_BLOCK, lds));
-            else if (media) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, true, false>, TRAV_BLOCK, lds));
-            else if (s->plain) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, false, true>, TRAV_BLOCK, lds));
-            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, false, false>, TRAV_BLOCK, lds));
+#define OCC(M, P) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_paths_lockstep<false, M, P>, TRAV_BLOCK, lds))
+            if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) OCC(RT_MEDIA_NONE, true); else OCC(RT_MEDIA_NONE, false); }
+            else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) OCC(RT_MEDIA_FLAT, true); else OCC(RT_MEDIA_FLAT, false); }
+            else { if (s->plain) OCC(RT_MEDIA_ANY, true); else OCC(RT_MEDIA_ANY, false); }
+#undef OCC
         }
         if (per_cu < 1) per_cu = 1;
         s->path_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
@@ -884,10 +893,11 @@ static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocu
     if (nocull) d.nodes = s->nodes_nocull;
     const uint32_t waves = (a.n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     if (!s->has_bvh) {
-        const bool media = !s->media.empty();
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
-        if (count) { if (media) LOCKSTEP(true, true); else LOCKSTEP(true, false); }
-        else { if (media) LOCKSTEP(false, true); else LOCKSTEP(false, false); }
+        if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
+        else if (s->media_mode == RT_MEDIA_NONE) LOCKSTEP(false, RT_MEDIA_NONE);
+        else if (s->media_mode == RT_MEDIA_FLAT) LOCKSTEP(false, RT_MEDIA_FLAT);
+        else LOCKSTEP(false, RT_MEDIA_ANY);
 #undef LOCKSTEP
     } else {
         HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
@@ -896,10 +906,11 @@ static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocu
         // launch is small, so that the rays spread over the whole device instead of queueing up behind a few waves
         TravArgs sized = a;
         sized.chunk = std::max(64u, std::min(RT_CHUNK, (a.n / std::max(1u, s->persist_waves) + 63u) / 64u * 64u));
-        const bool media = !s->media.empty();
 #define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, sized, s->d_count + 4, s->d_tallies)
-        if (count) { if (media) PERSIST(true, true); else PERSIST(true, false); }
-        else { if (media) PERSIST(false, true); else PERSIST(false, false); }
+        if (count) PERSIST(true, RT_MEDIA_ANY);
+        else if (s->media_mode == RT_MEDIA_NONE) PERSIST(false, RT_MEDIA_NONE);
+        else if (s->media_mode == RT_MEDIA_FLAT) PERSIST(false, RT_MEDIA_FLAT);
+        else PERSIST(false, RT_MEDIA_ANY);
 #undef PERSIST
     }
     HIP_TRY(hipGetLastError());
@@ -1040,7 +1051,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                        (o->max_depth == 0 && o->spp_count > 0) ? 0.0 : -0.0);
     if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 64, sm));
 
-    const bool lean_paths = s->plain && s->media.empty();
+    const bool lean_paths = s->plain && s->media_mode == RT_MEDIA_NONE;
     const bool fused = !s->has_bvh && !(o->flags & RT_FLAG_QUEUES) && ((o->flags & RT_FLAG_WHOLE_PATHS) != 0 || lean_paths);
     if (o->max_depth > 0 && o->spp_count > 0 && fused) {
         // whole paths in one kernel, batch after batch; a batch is as many samples of every pixel as fit the budget
@@ -1067,10 +1078,10 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
 #define PATH_ARGS d, *cam, o->seed, npix, o->spp_begin + b * spb, nb, o->max_depth, o->background[0], o->background[1], \
                   o->background[2], s->lum_r, s->lum_g, s->lum_b, s->d_count + 4, (unsigned long long*)(s->d_count + 8), s->d_tallies
 #define PATHS(C, M, P) hipLaunchKernelGGL((k_paths_lockstep<C, M, P>), dim3(grid), dim3(TRAV_BLOCK), levels_lds(s, TRAV_BLOCK), sm, PATH_ARGS)
-            const bool media = !s->media.empty();
-            if (count) PATHS(true, true, false);  // counting passes need no speed: one instantiation serves all scenes
-            else if (media) { if (s->plain) PATHS(false, true, true); else PATHS(false, true, false); }
-            else { if (s->plain) PATHS(false, false, true); else PATHS(false, false, false); }
+            if (count) PATHS(true, RT_MEDIA_ANY, false);  // counting passes need no speed: one instantiation serves all scenes
+            else if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) PATHS(false, RT_MEDIA_NONE, true); else PATHS(false, RT_MEDIA_NONE, false); }
+            else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) PATHS(false, RT_MEDIA_FLAT, true); else PATHS(false, RT_MEDIA_FLAT, false); }
+            else { if (s->plain) PATHS(false, RT_MEDIA_ANY, true); else PATHS(false, RT_MEDIA_ANY, false); }
 #undef PATHS
 #undef PATH_ARGS
             e = hipGetLastError();

@@ -534,7 +534,13 @@ RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels
     return n.skip;
 }
 
-template <bool MEDIA, bool COUNT, bool LOCKSTEP, class Src>
+// MEDIA says which ConstantMedium entries the tree may hold: RT_MEDIA_NONE, RT_MEDIA_FLAT (every boundary is
+// nothing but spheres, quads and triangles, so the nested walk below is never needed and costs the kernel no
+// registers) or RT_MEDIA_ANY.
+#define RT_MEDIA_NONE 0
+#define RT_MEDIA_FLAT 1
+#define RT_MEDIA_ANY 2
+template <int MEDIA, bool COUNT, bool LOCKSTEP, class Src>
 RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, const Levels& L, RngPos& rng, Best& best,
                 Ray& cur, uint32_t& cur_chain, Tally& tally);
 
@@ -548,7 +554,7 @@ RT_HD bool boundary_two_passes(const DScene& S, const Src& src, uint32_t i, cons
     for (int pass = 0; pass < 2 && ok; ++pass) {
         Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
         lv_set(L, n.level + 1u, lo, RT_INF);
-        walk<false, COUNT, LOCKSTEP>(S, src, i + 1u, n.skip, L, rng, b, cur, cur_chain, tally);
+        walk<RT_MEDIA_NONE, COUNT, LOCKSTEP>(S, src, i + 1u, n.skip, L, rng, b, cur, cur_chain, tally);
         ok = b.ref != RT_NO_HIT;
         if (pass == 0) t1 = b.t; else t2 = b.t;
         lo = b.t + 0.0001;
@@ -592,9 +598,12 @@ RT_HD void two_min_add_flat(TwoMin& w, double t, bool on) {
     w.m2 = lower ? (old_beyond ? w.m1 : w.m2) : ((upper & beyond) ? m2_upper : w.m2);
     w.m1 = lower ? t : w.m1;
 }
-template <bool COUNT, bool LOCKSTEP, class Src>
-RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const Node& n, Ray& cur, uint32_t& cur_chain,
-                             Tally& tally, double& t1, double& t2, bool& lost) {
+// SECOND = false: the scan described above.  SECOND = true: the second pass on its own, for the undecided cases --
+// the smallest value any primitive offers that is >= lo (into t2); no bookkeeping, and no counting (the scan before
+// it has counted both passes).
+template <bool COUNT, bool LOCKSTEP, bool SECOND, class Src>
+RT_HD bool boundary_scan(const DScene& S, const Src& src, uint32_t i, const Node& n, Ray& cur, uint32_t& cur_chain,
+                         Tally& tally, double lo, double& t1, double& t2, bool& lost) {
     TwoMin w; w.m1 = RT_INF; w.m2 = RT_INF; w.dirty = false; w.lost = false;
     uint32_t tests = 0, bytes = 0;
     for (uint32_t j = i + 1u; j < n.skip;) {
@@ -602,7 +611,7 @@ RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const 
         if (r.chain != cur_chain) { cur = ray_in_chain(S, src.world(), r.chain); cur_chain = r.chain; }
         if (r.kind == RT_NODE_CULL) {
             if (LOCKSTEP) j = j + 1u;
-            else j = cull_pass<COUNT>(S, j, 1u, cur, -RT_INF, RT_INF, tally) ? j + 1u : r.skip;
+            else j = cull_pass<COUNT && !SECOND>(S, j, 1u, cur, -RT_INF, RT_INF, tally) ? j + 1u : r.skip;
             continue;
         }
         const uint32_t last = r.first + r.count;
@@ -617,8 +626,14 @@ RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const 
                 if (!(disc < 0.0)) {
                     double sq = sqrt(disc);
                     double r1 = (h - sq) / cur.a, r2 = (h + sq) / cur.a;
-                    if (-RT_INF <= r1 && r1 < RT_INF) two_min_add(w, r1);
-                    if (-RT_INF <= r2 && r2 < RT_INF) two_min_add(w, r2);
+                    const bool ok1 = -RT_INF <= r1 && r1 < RT_INF, ok2 = -RT_INF <= r2 && r2 < RT_INF;
+                    if (SECOND) {
+                        if (ok1 && r1 >= lo) w.m2 = fmin(w.m2, r1);
+                        if (ok2 && r2 >= lo) w.m2 = fmin(w.m2, r2);
+                    } else {
+                        if (ok1) two_min_add(w, r1);
+                        if (ok2) two_min_add(w, r2);
+                    }
                 }
             }
             if (COUNT) { tests += r.count; bytes += 40u * r.count; }
@@ -633,17 +648,25 @@ RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const 
                     const uint32_t ax = S.quad_axis[k];
                     const bool hit = (ax != 0u && tame) ? quad_axis_t(g, ax, cur, -RT_INF, RT_INF, t)
                                                         : quad_flat_t(g, cur, -RT_INF, RT_INF, t);
-                    two_min_add_flat(w, t, hit);
+                    if (SECOND) w.m2 = (hit & (t >= lo)) ? fmin(w.m2, t) : w.m2;
+                    else two_min_add_flat(w, t, hit);
                 }
             } else {
                 for (uint32_t k = r.first; k < last; ++k) {
                     double t;
-                    if (planar_t(load_planar(base + 8u * k), is_tri, cur, -RT_INF, RT_INF, t)) two_min_add(w, t);
+                    if (planar_t(load_planar(base + 8u * k), is_tri, cur, -RT_INF, RT_INF, t)) {
+                        if (SECOND) { if (t >= lo) w.m2 = fmin(w.m2, t); }
+                        else two_min_add(w, t);
+                    }
                 }
             }
             if (COUNT) { tests += r.count; bytes += 136u * r.count; }
         }
         j = j + 1u;
+    }
+    if (SECOND) {
+        t2 = w.m2;
+        return w.m2 < RT_INF;
     }
     const bool first = w.m1 < RT_INF;
     if (COUNT) {  // what the two passes would have tested: the second runs only after a first hit
@@ -656,22 +679,23 @@ RT_HD bool boundary_one_pass(const DScene& S, const Src& src, uint32_t i, const 
     lost = w.lost;
     return first && w.m2 < RT_INF;
 }
-// Dispatch: entries of a MEDIUM record with count == 1 have a boundary the one-pass scan can handle (set where the
-// device records are built).
-template <bool COUNT, bool LOCKSTEP, class Src>
+// Dispatch: entries of a MEDIUM record with count == 1 have a boundary the scan can handle (set where the device
+// records are built).  ANY = false promises that every medium of the scene is of that kind.
+template <bool COUNT, bool LOCKSTEP, bool ANY, class Src>
 RT_HD bool boundary_hits(const DScene& S, const Src& src, uint32_t i, const Node& n, const Levels& L, RngPos& rng,
                          Ray& cur, uint32_t& cur_chain, Tally& tally, double& t1, double& t2) {
-    if (n.count == 1u) {
-        bool lost;
-        bool ok = boundary_one_pass<COUNT, LOCKSTEP>(S, src, i, n, cur, cur_chain, tally, t1, t2, lost);
+    if (!ANY || n.count == 1u) {
+        bool lost = false;
+        bool ok = boundary_scan<COUNT, LOCKSTEP, false>(S, src, i, n, cur, cur_chain, tally, 0.0, t1, t2, lost);
         if (!lost) return ok;
 #if !defined(__HIP_DEVICE_COMPILE__)
         host_fallback_count()++;
 #endif
-        Tally unused; unused.node_tests = 0; unused.prim_tests = 0; unused.prim_bytes = 0; unused.cull_tests = 0;
-        return boundary_two_passes<false, LOCKSTEP>(S, src, i, n, L, rng, cur, cur_chain, unused, t1, t2);
+        // undecided: now that the first hit is known, the second from a scan of its own
+        return boundary_scan<false, LOCKSTEP, true>(S, src, i, n, cur, cur_chain, tally, t1 + 0.0001, t1, t2, lost);
     }
-    return boundary_two_passes<COUNT, LOCKSTEP>(S, src, i, n, L, rng, cur, cur_chain, tally, t1, t2);
+    if constexpr (ANY) return boundary_two_passes<COUNT, LOCKSTEP>(S, src, i, n, L, rng, cur, cur_chain, tally, t1, t2);
+    return false;
 }
 
 // Walks entries [i, iend) of the flattened tree in order, which is the order of the reference's recursion:
@@ -688,7 +712,7 @@ RT_HD bool boundary_hits(const DScene& S, const Src& src, uint32_t i, const Node
 // the per-lane branches are dropped and all scene data comes through scalar loads.
 // CULL entries are passed over there without testing: a lane that failed the box could not leave the common
 // sequence anyway, and incoherent rays practically never fail it all together.
-template <bool MEDIA, bool COUNT, bool LOCKSTEP, class Src>
+template <int MEDIA, bool COUNT, bool LOCKSTEP, class Src>
 RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, const Levels& L, RngPos& rng, Best& best,
                 Ray& cur, uint32_t& cur_chain, Tally& tally) {
     for (;;) {
@@ -718,14 +742,14 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
             if (LOCKSTEP) i = i + 1u;
             else i = cull_pass<COUNT>(S, i, 1u, cur, s, e, tally) ? i + 1u : n.skip;
         } else if (n.kind == RT_NODE_MEDIUM) {
-            if constexpr (MEDIA) {
+            if constexpr (MEDIA != RT_MEDIA_NONE) {
                 // ConstantMedium::hit, constant_medium.rs:46-93
                 if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
                 const rt_medium m = S.media[n.first];
                 const double ray_length = sqrt(cur.a);  // of the ray the medium itself receives
                 double t1 = 0.0, t2 = 0.0;
                 const uint32_t i0 = LOCKSTEP ? wave_first(i) : i;
-                if (boundary_hits<COUNT, LOCKSTEP>(S, src, i0, n, L, rng, cur, cur_chain, tally, t1, t2)) {
+                if (boundary_hits<COUNT, LOCKSTEP, MEDIA == RT_MEDIA_ANY>(S, src, i0, n, L, rng, cur, cur_chain, tally, t1, t2)) {
                     t1 = fmax(t1, s);
                     t2 = fmin(t2, e);
                     t1 = fmax(t1, 0.0);
@@ -758,7 +782,7 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
 }
 
 // world.hit(ray, tmin..tmax) (camera.rs:363): returns the closest hit as (t, ref, chain).
-template <bool COUNT, bool LOCKSTEP, bool MEDIA = true, class Src>
+template <bool COUNT, bool LOCKSTEP, int MEDIA = RT_MEDIA_ANY, class Src>
 RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax, const Levels& L, RngPos& rng,
                        Tally& tally) {
     Best best; best.t = RT_INF; best.ref = RT_NO_HIT; best.chain = 0;
@@ -798,9 +822,9 @@ RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const 
     lv_set(L, 0u, tmin, tmax);
 }
 // One entry of the tree for a lane in RT_ST_NODE.
-// MEDIA = false is for scenes without a ConstantMedium: the medium code, its random draw and its logarithm then
+// MEDIA = RT_MEDIA_NONE is for scenes without a ConstantMedium: the medium code, its random draw and its logarithm then
 // cost the kernel no registers.
-template <bool COUNT, bool MEDIA = true, class Src>
+template <bool COUNT, int MEDIA = RT_MEDIA_ANY, class Src>
 RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Levels& L, RngPos& rng, Tally& tally) {
     if (ln.i >= S.n_nodes) { ln.state = RT_ST_DONE; return; }
     // The whole 128-byte record at once, whatever its kind: the boxes and the leaf's run sit in the same cache line
@@ -852,7 +876,7 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         ln.i = slab3(b0, b1, b2, ln.cur, cs, ce) ? ln.i + 1u : n.skip;
         return;
     }
-    if (MEDIA && n.kind == RT_NODE_MEDIUM) {
+    if (MEDIA != RT_MEDIA_NONE && n.kind == RT_NODE_MEDIUM) {
         // A medium costs several times what any other entry does (two boundary hits, a random draw, a logarithm),
         // and the wavefront pays for it whenever a single lane gets here: the lane waits in RT_ST_MEDIUM until the
         // caller has collected enough of them for one lane_medium_step.
@@ -877,7 +901,7 @@ RT_HD void lane_chain_step(const DScene& S, const Src& src, Lane& ln) {
 }
 // The MEDIUM entry a lane in RT_ST_MEDIUM stands on: ConstantMedium::hit, constant_medium.rs:46-93 (same steps as in
 // walk()).
-template <bool COUNT, class Src>
+template <bool COUNT, bool ANY = true, class Src>
 RT_HD void lane_medium_step(const DScene& S, const Src& src, Lane& ln, const Levels& L, RngPos& rng, Tally& tally) {
     const Node n = load_node(S, ln.i);
     const double2 iv = lv_get(L, n.level);
@@ -886,7 +910,7 @@ RT_HD void lane_medium_step(const DScene& S, const Src& src, Lane& ln, const Lev
     const rt_medium m = S.media[n.first];
     const double ray_length = sqrt(ln.cur.a);  // lane_node_step has put the ray into the entry's chain
     double t1 = 0.0, t2 = 0.0;
-    if (boundary_hits<COUNT, false>(S, src, ln.i, n, L, rng, ln.cur, ln.cur_chain, tally, t1, t2)) {
+    if (boundary_hits<COUNT, false, ANY>(S, src, ln.i, n, L, rng, ln.cur, ln.cur_chain, tally, t1, t2)) {
         t1 = fmax(t1, s);
         t2 = fmin(t2, e);
         t1 = fmax(t1, 0.0);
