@@ -111,7 +111,7 @@ __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long lo
 // world.hit(ray, 0.001..inf) for every queued path (camera.rs:363), for trees WITHOUT BVH entries: one lane per
 // ray, all lanes visit the same entries in the same order, scene data comes through scalar loads.
 template <bool COUNT, int MEDIA>
-__global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
+__global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_lockstep(DScene S, T
 #define RT_MEDIUM_THRESHOLD 18
 #define RT_CHAIN_THRESHOLD 12
 template <bool COUNT, int MEDIA>
-__global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
+__global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
