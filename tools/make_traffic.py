@@ -25,7 +25,9 @@ def main():
             if not k["dispatches"] or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
                 continue
             base = name.split("<")[0]
-            if name.endswith("<true>"):   # the instantiation with work counters only runs in the untimed counting pass
+            # the traverse / whole-path instantiations whose first template argument (COUNT) is true only run in the
+            # untimed counting passes
+            if base != "k_shade" and "<true" in name:
                 continue
             entry[base + "_hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / k["dispatches"]
             entry[base + "_avg_ms"] = k["avg_ms"]
