@@ -22,6 +22,7 @@ WORKLOADS = {  # BASELINE.json configs -> (scene function key, width, spp)
 }
 S_NODE, S_STATE, S_HIT = 64, 88, 56  # algorithmic bytes: BVH entry, path state, hit record
 HBM_PEAK_GBS = 8000.0
+FP64_PEAK_TFLOPS = 78.6
 
 
 def cpu_baseline(config, width, max_seconds=20.0):
@@ -133,6 +134,8 @@ def main():
         done = {"node_visits_per_ray": dst["node_tests"] / dst["rays"], "cull_tests_per_ray": dst["cull_tests"] / dst["rays"],
                 "prim_tests_per_ray": dst["prim_tests"] / dst["rays"], "prim_bytes_per_ray": dst["prim_bytes"] / dst["rays"],
                 "reference_prim_tests_per_ray": cst["prim_tests"] / cst["rays"]}
+        # algorithmic flops per ray: 18 per box test, the primitive tests as counted, ~100 for shading one bounce
+        flops_ray = 18.0 * n_node + cst["prim_flops"] / cst["rays"] + 100.0
         b_trav = S_NODE * n_node + prim_bytes + S_STATE + S_HIT        # traverse+intersect launch
         b_ray = S_NODE * n_node + prim_bytes + 2 * S_STATE + 2 * S_HIT  # whole bounce
         rays_local = sum(s["rays"] for s in stats)
@@ -167,6 +170,12 @@ def main():
                          "traverse_share_of_step": ms_trav / (elapsed * 1e3),
                          "shade_ms_per_step": sum(s["ms_shade"] for s in stats) / args.steps,
                          "work_done_with_cull_boxes": done},
+            # the bound that actually binds (all scenes are cache-resident): whole-step algorithmic flops against
+            # the FP64 vector peak, which counts an FMA as two flops although contraction is not allowed here
+            "roofline_fp64": {"bound": "fp64 valu", "achieved": total_rays / elapsed * flops_ray / 1e12 / world,
+                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+                              "frac": total_rays / elapsed * flops_ray / 1e12 / world / FP64_PEAK_TFLOPS,
+                              "flops_per_ray": flops_ray},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(key, width)

@@ -157,6 +157,8 @@ typedef struct rt_stats {
     uint64_t cull_tests; /* conservative cull-box tests (not in the reference), only with RT_FLAG_COUNTERS */
     uint64_t prim_bytes; /* bytes of the primitive records those calls read (sphere 40, quad/triangle 136, quadric 88,
                             medium 16), only with RT_FLAG_COUNTERS */
+    uint64_t prim_flops; /* algorithmic flops of those calls (sphere 35, quad/triangle 60, quadric 70, medium 30 each),
+                            only with RT_FLAG_COUNTERS */
     double ms_total;     /* device time of the whole call */
     double ms_traverse;  /* summed duration of the traverse+intersect launches (HIP events) */
     double ms_shade;     /* summed duration of the shade+compact launches */

@@ -99,12 +99,11 @@ __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, 
     tmax = a.tmax ? a.tmax[idx] : RT_INF;
 }
 __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long long* tallies) {
-    unsigned long long a = tally.node_tests, b = tally.prim_tests, c = tally.prim_bytes, d = tally.cull_tests;
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); d += __shfl_down(d, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&tallies[0], a); atomicAdd(&tallies[1], b); atomicAdd(&tallies[2], c); atomicAdd(&tallies[3], d);
+    unsigned long long v[5] = {tally.node_tests, tally.prim_tests, tally.prim_bytes, tally.cull_tests, tally.prim_flops};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&tallies[k], v[k]);
     }
 }
 
@@ -114,7 +113,7 @@ template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     if (idx < a.n) {
         RngPos rng;
         double tmin, tmax;
@@ -142,7 +141,7 @@ template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t pool_next = 0, pool_end = 0;
@@ -230,7 +229,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 2) k_paths_lockstep(DScene S, rt_c
                                                                    unsigned long long* counters,
                                                                    unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t pool_next = 0, pool_end = 0;
@@ -440,7 +439,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_samples(DScene S, rt_camer
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
     V3 o, d;
     camera_ray(cam, pixel[i] % cam.width, pixel[i] / cam.width, rng, o, d);
@@ -1182,6 +1181,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         st.prim_tests = h[1];
         st.prim_bytes = h[2];
         st.cull_tests = h[3];
+        st.prim_flops = h[4];
     }
     if (stats) *stats = st;
     return RT_OK;
@@ -1276,7 +1276,7 @@ int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, 
         for (int r = 0; r < n; ++r) {
             const rt_stats& a = sh[(size_t)r].st;
             t.paths += a.paths; t.rays += a.rays; t.node_tests += a.node_tests; t.prim_tests += a.prim_tests;
-            t.cull_tests += a.cull_tests; t.prim_bytes += a.prim_bytes;
+            t.cull_tests += a.cull_tests; t.prim_bytes += a.prim_bytes; t.prim_flops += a.prim_flops;
             t.ms_total = std::max(t.ms_total, a.ms_total); t.ms_traverse = std::max(t.ms_traverse, a.ms_traverse);
             t.ms_shade = std::max(t.ms_shade, a.ms_shade); t.ms_paths = std::max(t.ms_paths, a.ms_paths);
             t.traverse_launches += a.traverse_launches; t.path_launches += a.path_launches;

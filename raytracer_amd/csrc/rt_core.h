@@ -251,6 +251,7 @@ struct Best {
 };
 struct Tally {
     uint32_t node_tests, prim_tests, prim_bytes, cull_tests;
+    uint32_t prim_flops;  // algorithmic: 35 per sphere test, 60 per quad / triangle, 70 per quadric, 30 per medium
 };
 
 // True when every active lane of the wavefront holds the same x (returned in `first`).  Records addressed through
@@ -451,7 +452,7 @@ RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t co
     if (kind == RT_NODE_TRIANGLES) {
         const double2* base = reinterpret_cast<const double2*>(S.tris);
         for (uint32_t k = first; k < last; ++k) {
-            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; tally.prim_flops += 60u; }
             double t;
             if (tri_t(load_planar(base + 8u * k), cur, s, e, t)) {
                 best.t = t; best.ref = make_ref(RT_NODE_TRIANGLES, k); best.chain = chain;
@@ -464,7 +465,7 @@ RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t co
             // a wavefront whose rays are not all tame (never, in a render) takes the general form for all of them
             const bool tame = wave_all(ray_is_tame(cur));
             for (uint32_t k = first; k < last; ++k) {
-                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; tally.prim_flops += 60u; }
                 double t;
                 const Planar g = load_planar(base + 8u * k);
                 const uint32_t ax = S.quad_axis[k];
@@ -477,7 +478,7 @@ RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t co
             }
         } else {
             for (uint32_t k = first; k < last; ++k) {
-                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; }
+                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 136u; tally.prim_flops += 60u; }
                 double t;
                 if (quad_t(load_planar(base + 8u * k), cur, s, e, t)) {
                     best.t = t; best.ref = make_ref(RT_NODE_QUADS, k); best.chain = chain;
@@ -488,7 +489,7 @@ RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t co
     } else if (kind == RT_NODE_SPHERES) {
         const double2* base = reinterpret_cast<const double2*>(S.spheres);
         for (uint32_t k = first; k < last; ++k) {
-            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 40u; }
+            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 40u; tally.prim_flops += 35u; }
             double t;
             if (sphere_t(base + 2u * k, cur, s, e, t)) {
                 best.t = t; best.ref = make_ref(RT_NODE_SPHERES, k); best.chain = chain;
@@ -498,7 +499,7 @@ RT_HD void run_prims(const DScene& S, uint32_t kind, uint32_t first, uint32_t co
     } else {  // RT_NODE_QUADRICS
         const double2* base = reinterpret_cast<const double2*>(S.quadrics);
         for (uint32_t k = first; k < last; ++k) {
-            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
+            if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; tally.prim_flops += 70u; }
             double t;
             if (quadric_t(base + 5u * k, cur, s, e, t)) {
                 best.t = t; best.ref = make_ref(RT_NODE_QUADRICS, k); best.chain = chain;
@@ -605,7 +606,7 @@ template <bool COUNT, bool LOCKSTEP, bool SECOND, class Src>
 RT_HD bool boundary_scan(const DScene& S, const Src& src, uint32_t i, const Node& n, Ray& cur, uint32_t& cur_chain,
                          Tally& tally, double lo, double& t1, double& t2, bool& lost) {
     TwoMin w; w.m1 = RT_INF; w.m2 = RT_INF; w.dirty = false; w.lost = false;
-    uint32_t tests = 0, bytes = 0;
+    uint32_t tests = 0, bytes = 0, flops = 0;
     for (uint32_t j = i + 1u; j < n.skip;) {
         const Node r = load_node(S, LOCKSTEP ? wave_first(j) : j);
         if (r.chain != cur_chain) { cur = ray_in_chain(S, src.world(), r.chain); cur_chain = r.chain; }
@@ -636,7 +637,7 @@ RT_HD bool boundary_scan(const DScene& S, const Src& src, uint32_t i, const Node
                     }
                 }
             }
-            if (COUNT) { tests += r.count; bytes += 40u * r.count; }
+            if (COUNT) { tests += r.count; bytes += 40u * r.count; flops += 35u * r.count; }
         } else {
             const bool is_tri = r.kind == RT_NODE_TRIANGLES;
             const double2* base = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads);
@@ -660,7 +661,7 @@ RT_HD bool boundary_scan(const DScene& S, const Src& src, uint32_t i, const Node
                     }
                 }
             }
-            if (COUNT) { tests += r.count; bytes += 136u * r.count; }
+            if (COUNT) { tests += r.count; bytes += 136u * r.count; flops += 60u * r.count; }
         }
         j = j + 1u;
     }
@@ -672,6 +673,7 @@ RT_HD bool boundary_scan(const DScene& S, const Src& src, uint32_t i, const Node
     if (COUNT) {  // what the two passes would have tested: the second runs only after a first hit
         tally.prim_tests += first ? 2u * tests : tests;
         tally.prim_bytes += first ? 2u * bytes : bytes;
+        tally.prim_flops += first ? 2u * flops : flops;
     }
     if (first && w.m1 >= w.m1 + 0.0001) w.m2 = fmin(w.m2, w.m1);  // 0.0001 below the spacing of doubles at m1
     t1 = w.m1;
@@ -744,7 +746,7 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
         } else if (n.kind == RT_NODE_MEDIUM) {
             if constexpr (MEDIA != RT_MEDIA_NONE) {
                 // ConstantMedium::hit, constant_medium.rs:46-93
-                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
+                if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; tally.prim_flops += 30u; }
                 const rt_medium m = S.media[n.first];
                 const double ray_length = sqrt(cur.a);  // of the ray the medium itself receives
                 double t1 = 0.0, t2 = 0.0;
@@ -906,7 +908,7 @@ RT_HD void lane_medium_step(const DScene& S, const Src& src, Lane& ln, const Lev
     const Node n = load_node(S, ln.i);
     const double2 iv = lv_get(L, n.level);
     const double s = iv.x, e = fmin(iv.y, ln.best.t);
-    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; }
+    if (COUNT) { tally.prim_tests++; tally.prim_bytes += 16u; tally.prim_flops += 30u; }
     const rt_medium m = S.media[n.first];
     const double ray_length = sqrt(ln.cur.a);  // lane_node_step has put the ray into the entry's chain
     double t1 = 0.0, t2 = 0.0;
@@ -939,7 +941,7 @@ RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
         const double2* rec = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads) + 8u * ln.k;
         const Planar g0 = load_planar(rec);
         const Planar g1 = load_planar(rec + (two ? 8u : 0u));
-        if (COUNT) { tally.prim_tests += two ? 2u : 1u; tally.prim_bytes += two ? 272u : 136u; }
+        if (COUNT) { tally.prim_tests += two ? 2u : 1u; tally.prim_bytes += two ? 272u : 136u; tally.prim_flops += two ? 120u : 60u; }
         if (planar_t(g0, is_tri, ln.cur, ln.s, ln.e, t)) {
             ln.best.t = t; ln.best.ref = make_ref(ln.kind, ln.k); ln.best.chain = ln.cur_chain;
             ln.e = t;
@@ -955,7 +957,7 @@ RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
         double2 q[8];
 #pragma unroll
         for (uint32_t j = 0; j < 8u; ++j) q[j] = rec[j < 2u * done ? j : 0u];
-        if (COUNT) { tally.prim_tests += done; tally.prim_bytes += 40u * done; }
+        if (COUNT) { tally.prim_tests += done; tally.prim_bytes += 40u * done; tally.prim_flops += 35u * done; }
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
             if (j < done && sphere_t(q + 2u * j, ln.cur, ln.s, ln.e, t)) {
@@ -967,7 +969,7 @@ RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
         if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
         return;
     } else {
-        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; }
+        if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; tally.prim_flops += 70u; }
         if (quadric_t(reinterpret_cast<const double2*>(S.quadrics) + 5u * ln.k, ln.cur, ln.s, ln.e, t)) {
             ln.best.t = t; ln.best.ref = make_ref(RT_NODE_QUADRICS, ln.k); ln.best.chain = ln.cur_chain;
             ln.e = t;
