@@ -53,7 +53,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--config", default="C2", help="a BASELINE.json configuration (C1..C5, the metric's workloads) or the "
+                    "name of another scene program of the reference, run at the reference's own settings")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per GPU (invalidates the metric)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch-paths", type=int, default=0)
@@ -75,7 +76,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from raytracer_amd import HostBuilder, camera_new, scenes
-    key, width, spp = WORKLOADS[args.config]
+    if args.config in WORKLOADS:
+        key, width, spp = WORKLOADS[args.config]
+    elif args.config in scenes.SCENES:
+        probe = scenes.build(args.config, HostBuilder())
+        key, width, spp = args.config, probe.width, probe.spp
+        probe.builder.close()
+    else:
+        raise SystemExit(f"unknown --config {args.config}: one of {sorted(WORKLOADS)} or {sorted(scenes.SCENES)}")
     width = args.width or width
     spp = args.spp or spp
     spec = scenes.build(key, HostBuilder(), width=width)
