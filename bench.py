@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--whole-paths", action="store_true", help="RT_FLAG_WHOLE_PATHS: one kernel per batch (BVH-free scenes)")
     ap.add_argument("--queues", action="store_true", help="RT_FLAG_QUEUES: the queue-based schedule whatever the scene")
+    ap.add_argument("--split-bounce", action="store_true", help="RT_FLAG_SPLIT_BOUNCE: separate traverse and shade launches")
     args = ap.parse_args()
 
     import torch
@@ -100,7 +101,8 @@ def main():
 
         def render_range(begin, count):
             st.update(scene.render_into(cam, count, spec.max_depth, spec.background, film.data_ptr(), spp_begin=begin,
-                                        batch_paths=args.batch_paths, whole_paths=schedule))
+                                        batch_paths=args.batch_paths, whole_paths=schedule,
+                                        split_bounce=args.split_bounce))
 
         render_sharded(render_range, film, spp * world)  # rank r renders samples [r*spp, (r+1)*spp), then RCCL all-reduce
         return st
@@ -152,6 +154,10 @@ def main():
             kernel = "k_paths_lockstep"
             launches, ms_trav, b_kernel = sum(s["path_launches"] for s in stats), \
                 sum(s["ms_paths"] for s in stats), b_ray
+        elif sum(s["bounce_launches"] for s in stats) > 0:  # traverse + shade of one bounce in one kernel
+            kernel = "k_bounce_lockstep"
+            launches, ms_trav, b_kernel = sum(s["bounce_launches"] for s in stats), \
+                sum(s["ms_bounce"] for s in stats), b_ray
         else:
             kernel = "k_traverse_lockstep" if stats[0]["lockstep"] else "k_traverse_persistent"
             launches, ms_trav, b_kernel = sum(s["traverse_launches"] for s in stats), \

@@ -56,8 +56,9 @@ typedef struct rt_texture {
     uint32_t kind;
     uint32_t a;
     uint32_t b;
-    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_traverse_lockstep / k_paths_lockstep,
-                          otherwise k_traverse_persistent */
+    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep / k_traverse_lockstep /
+                          k_paths_lockstep, otherwise k_traverse_persistent */
+    uint32_t reserved;
     double color[3];
     double scale;
 } rt_texture;
@@ -69,8 +70,9 @@ enum rt_xform_kind {
 };
 typedef struct rt_xform_op {
     uint32_t kind;
-    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_traverse_lockstep / k_paths_lockstep,
-                          otherwise k_traverse_persistent */
+    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep / k_traverse_lockstep /
+                          k_paths_lockstep, otherwise k_traverse_persistent */
+    uint32_t reserved;
     double v[3];
 } rt_xform_op;
 /* A chain lists the instance transforms between the world and a node, outermost first.  Chain 0 is empty. */
@@ -148,6 +150,9 @@ typedef struct rt_render_opts {
                                   only Lambertian / DiffuseLight / Isotropic over solid colours), queues otherwise.
                                   The film is the same either way */
 #define RT_FLAG_QUEUES 8u      /* always the queue-based schedule */
+#define RT_FLAG_SPLIT_BOUNCE 16u /* queue-based schedule of a scene without BVH entries: one traverse and one shade
+                                    launch per bounce, as for scenes with BVH entries, instead of the single bounce
+                                    kernel that does both (the default there).  The film is the same either way */
 
 typedef struct rt_stats {
     uint64_t paths;      /* camera samples traced */
@@ -163,11 +168,15 @@ typedef struct rt_stats {
     double ms_traverse;  /* summed duration of the traverse+intersect launches (HIP events) */
     double ms_shade;     /* summed duration of the shade+compact launches */
     double ms_paths;     /* summed duration of the whole-path launches (scenes without BVH entries) */
+    double ms_bounce;    /* summed duration of the bounce launches: traverse, shade and compaction in one kernel
+                            (queue-based schedule of scenes without BVH entries) */
     uint32_t traverse_launches;
     uint32_t path_launches;
+    uint32_t bounce_launches;
     uint32_t bounces; /* most world.hit calls any one path made */
-    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_traverse_lockstep / k_paths_lockstep,
-                          otherwise k_traverse_persistent */
+    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep / k_traverse_lockstep /
+                          k_paths_lockstep, otherwise k_traverse_persistent */
+    uint32_t reserved;
 } rt_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */

@@ -403,6 +403,74 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
     }
 }
 
+// One whole bounce for trees WITHOUT BVH entries: the lockstep walk of k_traverse_lockstep followed, in the same
+// lane, by what k_shade does with the closest hit.  The hit never goes through memory and the path state is read
+// once; the walk's registers are dead by the time the material code starts, so the kernel keeps the walk's occupancy.
+#define BOUNCE_BLOCK 256
+template <int MEDIA, bool PLAIN>
+__global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_bounce_lockstep(
+    DScene S, uint64_t seed, uint32_t n, Queue q, Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
+    double* lum_b, double bgr, double bgg, double bgb, uint32_t iter, uint32_t max_depth) {
+    __shared__ uint32_t wave_total[BOUNCE_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    bool alive = false;
+    V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
+    uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
+    if (idx < n) {
+        RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32);
+        rp.pixel = q.pix[idx]; rp.sample = q.smp[idx]; rp.ctr = q.ctr[idx];
+        RaySoA src;
+        src.ox = q.ox; src.oy = q.oy; src.oz = q.oz; src.dx = q.dx; src.dy = q.dy; src.dz = q.dz; src.idx = idx;
+        const Best b = closest_hit<false, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
+        slot = q.slot[idx];
+        born = q.born[idx];
+        beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
+        if (b.ref == RT_NO_HIT) {
+            lum_r[slot] = beta.x * bgr; lum_g[slot] = beta.y * bgg; lum_b[slot] = beta.z * bgb;
+        } else {
+            pix = rp.pixel;
+            smp = rp.sample;
+            Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
+            Rec rec = finalize<false, PLAIN>(S, w, b);
+            Rng rng = rng_make(seed, pix, smp, rp.ctr);
+            V3 att, emit;
+            const rt_material m = S.mats[rec.mat];
+            if (!scatter<PLAIN>(S, m, w.d, rec, rng, nd, att, emit)) {
+                lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
+            } else if (iter - born + 1u == max_depth) {
+                lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;  // camera.rs:350-352
+            } else {
+                beta = beta * att;
+                no = rec.p;
+                ctr = rng.ctr;
+                alive = true;
+            }
+        }
+    }
+    unsigned long long mask = __ballot(alive);
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < BOUNCE_BLOCK / 64; ++k) { uint32_t c = wave_total[k]; wave_total[k] = tot; tot += c; }
+        block_base = tot ? atomicAdd(out_count, tot) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t dst = block_base + wave_total[wave] + prefix;
+        out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
+        out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
+        out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
+        out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
+        out.ctr[dst] = ctr;
+    }
+}
+
 // film[pix] += lum[s][pix] for s = 0.. in sample order: the running sum of camera.rs:258-264 (Point3::sum folds
 // from -0.0, point3/mod.rs:96-109; the host initialises the film with -0.0).
 __global__ void k_film_accumulate(const double* lum_r, const double* lum_g, const double* lum_b, uint32_t npix,
@@ -1115,6 +1183,8 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         if (qcap > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
         if ((rc = ensure_workspace(s, (size_t)qcap, (size_t)(bsize * nslots)))) return rc;
         std::vector<uint32_t> born_at(nbatches, 0);
+        // counting passes go through the separate kernels, which carry the counters
+        const bool bounce = !s->has_bvh && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
         Queue qin = s->qa, qout = s->qb;
         uint32_t n = 0, iter = 0, injected = 0, accumulated = 0;
         auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
@@ -1135,6 +1205,20 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             st.rays += n;
             HIP_TRY(hipMemsetAsync(s->d_count, 0, 4, sm));
             HIP_TRY(hipEventRecord(s->ev[1], sm));
+            if (bounce) {
+                DScene d = s->d;
+                if (o->flags & RT_FLAG_NO_CULL) d.nodes = s->nodes_nocull;
+#define BOUNCE_ARGS d, o->seed, n, qin, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
+                    o->background[1], o->background[2], iter, o->max_depth
+#define BOUNCE(M, P) hipLaunchKernelGGL((k_bounce_lockstep<M, P>), dim3((n + BOUNCE_BLOCK - 1) / BOUNCE_BLOCK), dim3(BOUNCE_BLOCK), \
+                                        levels_lds(s, BOUNCE_BLOCK), sm, BOUNCE_ARGS)
+                if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) BOUNCE(RT_MEDIA_NONE, true); else BOUNCE(RT_MEDIA_NONE, false); }
+                else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) BOUNCE(RT_MEDIA_FLAT, true); else BOUNCE(RT_MEDIA_FLAT, false); }
+                else { if (s->plain) BOUNCE(RT_MEDIA_ANY, true); else BOUNCE(RT_MEDIA_ANY, false); }
+#undef BOUNCE
+#undef BOUNCE_ARGS
+                HIP_TRY(hipEventRecord(s->ev[2], sm));
+            } else {
             TravArgs ta;
             std::memset(&ta, 0, sizeof ta);
             ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.n = n;
@@ -1145,16 +1229,22 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             if (s->plain) hipLaunchKernelGGL(k_shade<true>, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
             else hipLaunchKernelGGL(k_shade<false>, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
 #undef SHADE_ARGS
+            }
             HIP_TRY(hipEventRecord(s->ev[3], sm));
             HIP_TRY(hipMemcpyAsync(s->h_count, s->d_count, 4, hipMemcpyDeviceToHost, sm));
             HIP_TRY(hipStreamSynchronize(sm));
             HIP_TRY(hipGetLastError());
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
-            st.ms_traverse += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
-            st.ms_shade += ms;
-            st.traverse_launches++;
+            if (bounce) {
+                st.ms_bounce += ms;
+                st.bounce_launches++;
+            } else {
+                st.ms_traverse += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
+                st.ms_shade += ms;
+                st.traverse_launches++;
+            }
             n = *s->h_count;
             std::swap(qin, qout);
             iter++;
@@ -1279,7 +1369,9 @@ int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, 
             t.cull_tests += a.cull_tests; t.prim_bytes += a.prim_bytes; t.prim_flops += a.prim_flops;
             t.ms_total = std::max(t.ms_total, a.ms_total); t.ms_traverse = std::max(t.ms_traverse, a.ms_traverse);
             t.ms_shade = std::max(t.ms_shade, a.ms_shade); t.ms_paths = std::max(t.ms_paths, a.ms_paths);
+            t.ms_bounce = std::max(t.ms_bounce, a.ms_bounce);
             t.traverse_launches += a.traverse_launches; t.path_launches += a.path_launches;
+            t.bounce_launches += a.bounce_launches;
             t.bounces = std::max(t.bounces, a.bounces); t.lockstep = a.lockstep;
         }
         *stats = t;

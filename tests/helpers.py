@@ -54,8 +54,10 @@ def _sim_lib():
     if _SIM is None:
         so = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
         src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
-        core = os.path.join(ROOT, "raytracer_amd", "csrc", "rt_core.h")
-        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+        deps = [src] + [os.path.join(ROOT, *p) for p in (("raytracer_amd", "csrc", "rt_core.h"),
+                                                         ("raytracer_amd", "csrc", "rt_records.h"),
+                                                         ("include", "rt_amd.h"))]
+        if not os.path.exists(so) or os.path.getmtime(so) <= max(os.path.getmtime(d) for d in deps):
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-host-only", "-x", "hip", "-O2", "-std=c++17", "-fPIC",
                                    "-shared", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", so, src])
         _SIM = C.CDLL(so)

@@ -90,18 +90,22 @@ def test_per_sample_radiance_matches_oracle(gpu_scenes, cfg):
 
 
 @pytest.mark.parametrize("cfg", CONFIGS)
-@pytest.mark.parametrize("schedule", ["queues", "whole-paths"])
+@pytest.mark.parametrize("schedule", ["queues", "queues-split", "whole-paths"])
 def test_film_equals_sum_of_samples(gpu_scenes, cfg, schedule):
     """rt_render must give, bit for bit, the in-order sum of the per-sample radiances rt_trace_samples computes with
-    one lane per whole path -- on both schedules: the queue-based one (queues + compaction + film accumulation) and
-    whole paths in one kernel (on request, for scenes without BVH entries)."""
+    one lane per whole path -- on every schedule: the queue-based one (queues + compaction + film accumulation; for
+    scenes without BVH entries with one bounce kernel or, on request, with separate traverse and shade launches)
+    and whole paths in one kernel (on request, for scenes without BVH entries)."""
     hs, os_, scene = gpu_scenes(cfg)
     hc, _ = cameras(hs)
     spp = 3
     film, stats = scene.render(hc, spp, hs.max_depth, hs.background, spp_begin=5, batch_paths=2 * hc.width * hc.height,
-                               whole_paths=schedule == "whole-paths")  # forced either way
-    assert (stats["path_launches"] > 0) == (schedule == "whole-paths" and cfg in ("C2", "C3"))
-    assert (stats["traverse_launches"] > 0) != (stats["path_launches"] > 0)
+                               whole_paths=schedule == "whole-paths",  # forced either way
+                               split_bounce=schedule == "queues-split")
+    no_bvh = cfg in ("C2", "C3")
+    assert (stats["path_launches"] > 0) == (schedule == "whole-paths" and no_bvh)
+    assert (stats["bounce_launches"] > 0) == (schedule == "queues" and no_bvh)
+    assert sum(stats[k] > 0 for k in ("traverse_launches", "path_launches", "bounce_launches")) == 1
     npix = hc.width * hc.height
     pixel = np.tile(np.arange(npix, dtype=np.uint32), spp)
     sample = np.repeat(np.arange(5, 5 + spp, dtype=np.uint32), npix)
@@ -232,11 +236,11 @@ def test_full_size_headline_workload_properties():
         assert np.array_equal(film, again) and st2["rays"] == st["rays"]
         small_queue, st3 = scene.render(cam, spp, spec.max_depth, spec.background, batch_paths=3_000_000)
         assert np.array_equal(film, small_queue) and st3["rays"] == st["rays"]
-        assert st3["traverse_launches"] > st["traverse_launches"]
+        assert st3["bounce_launches"] > st["bounce_launches"] > 0
         whole, st4 = scene.render(cam, spp, spec.max_depth, spec.background, whole_paths=True)
         assert np.array_equal(film, whole) and st4["rays"] == st["rays"] and st4["path_launches"] > 0
-        queues, st5 = scene.render(cam, spp, spec.max_depth, spec.background, whole_paths=False)
-        assert np.array_equal(film, queues) and st5["traverse_launches"] > 0
+        split, st5 = scene.render(cam, spp, spec.max_depth, spec.background, whole_paths=False, split_bounce=True)
+        assert np.array_equal(film, split) and st5["traverse_launches"] > 0 and st5["bounce_launches"] == 0
         no_cull, _ = scene.render(cam, spp, spec.max_depth, spec.background, cull=False)
         assert np.array_equal(film, no_cull)
         a, sa = scene.render(cam, 100, spec.max_depth, spec.background, spp_begin=0)
