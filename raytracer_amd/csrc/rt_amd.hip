@@ -419,6 +419,14 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     bool alive = false;
     V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
     uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
+    // the three stretches below are entered by whole wavefronts: between them all 64 lanes are back together, which
+    // the shared rejection loop in the middle needs
+    bool hit = false;
+    Rec rec;
+    rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
+    rt_material m;
+    m.kind = RT_MAT_DIFFUSE_LIGHT; m.texture = 0; m.param = 0; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0;
+    V3 wd = mk(0, 0, 0);
     if (idx < n) {
         RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32);
         rp.pixel = q.pix[idx]; rp.sample = q.smp[idx]; rp.ctr = q.ctr[idx];
@@ -428,26 +436,31 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
         slot = q.slot[idx];
         born = q.born[idx];
         beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
+        pix = rp.pixel; smp = rp.sample; ctr = rp.ctr;
         if (b.ref == RT_NO_HIT) {
             lum_r[slot] = beta.x * bgr; lum_g[slot] = beta.y * bgg; lum_b[slot] = beta.z * bgb;
         } else {
-            pix = rp.pixel;
-            smp = rp.sample;
             Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
-            Rec rec = finalize<false, PLAIN>(S, w, b);
-            Rng rng = rng_make(seed, pix, smp, rp.ctr);
-            V3 att, emit;
-            const rt_material m = S.mats[rec.mat];
-            if (!scatter<PLAIN>(S, m, w.d, rec, rng, nd, att, emit)) {
-                lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
-            } else if (iter - born + 1u == max_depth) {
-                lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;  // camera.rs:350-352
-            } else {
-                beta = beta * att;
-                no = rec.p;
-                ctr = rng.ctr;
-                alive = true;
-            }
+            rec = finalize<false, PLAIN>(S, w, b);
+            m = S.mats[rec.mat];
+            wd = w.d;
+            hit = true;
+        }
+    }
+    const V3 ruv = wave_unit_vector(hit && scatter_wants_unit_vector<PLAIN>(m), (uint32_t)seed, (uint32_t)(seed >> 32),
+                                    pix, smp, ctr);
+    if (hit) {
+        Rng rng = rng_make(seed, pix, smp, ctr);
+        V3 att, emit;
+        if (!scatter_given<PLAIN>(S, m, wd, rec, rng, ruv, nd, att, emit)) {
+            lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
+        } else if (iter - born + 1u == max_depth) {
+            lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;  // camera.rs:350-352
+        } else {
+            beta = beta * att;
+            no = rec.p;
+            ctr = rng.ctr;
+            alive = true;
         }
     }
     unsigned long long mask = __ballot(alive);

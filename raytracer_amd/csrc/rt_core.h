@@ -103,28 +103,97 @@ RT_HD double rng_next01(Rng& r) {
     return unit_interval(bits);
 }
 RT_HD double rng_range(Rng& r, double lo, double hi) { return rng_next01(r) * (hi - lo) + lo; }
+RT_HD bool unit_vector_trial(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t c, V3& p);
 RT_HD V3 random_unit_vector(Rng& r) {  // point3/mod.rs:229-250
     // Draws ctr, ctr + 1, ctr + 2 of every trial lie in blocks ctr >> 1 and (ctr >> 1) + 1: both are generated for
     // all lanes alike and the three values picked by the parity of ctr.  Going through rng_next01 instead, lanes of
     // either parity would need their next block at different draws and a wavefront would run the generator three
     // times per trial, each time for half of its lanes.
     for (;;) {
-        const uint32_t c = r.ctr, b0 = c >> 1;
-        uint32_t w0[4] = {r.pixel, r.sample, b0, 0u}, w1[4] = {r.pixel, r.sample, b0 + 1u, 0u};
-        philox4x32_10(w0, r.k0, r.k1);
-        philox4x32_10(w1, r.k0, r.k1);
-        const uint64_t lo0 = ((uint64_t)w0[1] << 32) | w0[0], hi0 = ((uint64_t)w0[3] << 32) | w0[2];
-        const uint64_t lo1 = ((uint64_t)w1[1] << 32) | w1[0], hi1 = ((uint64_t)w1[3] << 32) | w1[2];
-        const bool odd = (c & 1u) != 0u;
-        double x = unit_interval(odd ? hi0 : lo0) * (1.0 - -1.0) + -1.0;
-        double y = unit_interval(odd ? lo1 : hi0) * (1.0 - -1.0) + -1.0;
-        double z = unit_interval(odd ? hi1 : lo1) * (1.0 - -1.0) + -1.0;
-        r.ctr = c + 3u;
+        V3 p;
+        const bool ok = unit_vector_trial(r.k0, r.k1, r.pixel, r.sample, r.ctr, p);
+        r.ctr += 3u;
         r.blk = 0xFFFFFFFFu;
-        V3 p = mk(x, y, z);
-        if (len2(p) < 1.0) return unit(p);
+        if (ok) return unit(p);
     }
 }
+// One trial of that loop at draw position c of a stream: the candidate point and whether it is accepted.
+RT_HD bool unit_vector_trial(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t c, V3& p) {
+    const uint32_t b0 = c >> 1;
+    uint32_t w0[4] = {pixel, sample, b0, 0u}, w1[4] = {pixel, sample, b0 + 1u, 0u};
+    philox4x32_10(w0, k0, k1);
+    philox4x32_10(w1, k0, k1);
+    const uint64_t lo0 = ((uint64_t)w0[1] << 32) | w0[0], hi0 = ((uint64_t)w0[3] << 32) | w0[2];
+    const uint64_t lo1 = ((uint64_t)w1[1] << 32) | w1[0], hi1 = ((uint64_t)w1[3] << 32) | w1[2];
+    const bool odd = (c & 1u) != 0u;
+    p.x = unit_interval(odd ? hi0 : lo0) * (1.0 - -1.0) + -1.0;
+    p.y = unit_interval(odd ? lo1 : hi0) * (1.0 - -1.0) + -1.0;
+    p.z = unit_interval(odd ? hi1 : lo1) * (1.0 - -1.0) + -1.0;
+    return len2(p) < 1.0;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double lane_pull(uint32_t src_lane, double v) {  // v of lane src_lane
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)(b >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// random_unit_vector for the lanes of a wavefront that `want` one, from each lane's own stream at `ctr` (advanced by
+// three draws per trial consumed, exactly as the loop above would).  Has to be called by all 64 lanes together.
+// The loop above keeps a whole wavefront going until its unluckiest lane is accepted (about six rounds for 64
+// lanes at an acceptance rate of pi/6, with ever fewer lanes doing anything useful).  Here, once no more than half
+// of the lanes are still waiting, the idle lanes run the waiting lanes' next trials for them -- lane j tries draw
+// position ctr + 3 * (j / m) of the (j % m)-th waiting lane's stream, m being the number of waiting lanes -- and each
+// waiting lane takes the first accepted of its trials: the same vector from the same draws in about three rounds.
+__device__ inline V3 wave_unit_vector(bool want, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t& ctr) {
+    const uint32_t lane = __lane_id();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    V3 p = mk(0.0, 0.0, 1.0);
+    bool pending = want;
+    for (;;) {
+        const unsigned long long mask = __ballot(pending);
+        if (mask == 0ull) break;
+        const uint32_t m = (uint32_t)__popcll(mask);
+        if (m > 32u) {  // not even two trials per waiting lane: everyone tries for itself
+            if (pending) {
+                V3 cand;
+                const bool ok = unit_vector_trial(k0, k1, pixel, sample, ctr, cand);
+                ctr += 3u;
+                if (ok) { p = cand; pending = false; }
+            }
+            continue;
+        }
+        const uint32_t per = 64u / m < 8u ? 64u / m : 8u;          // trials per waiting lane this round
+        const uint32_t rank = (uint32_t)__popcll(mask & below);     // waiting lanes before this one
+        // slot s < m learns which lane is the s-th waiting one (the others send their ids past slot m)
+        const uint32_t dst = pending ? rank : m + (lane - rank);
+        const uint32_t slot_owner = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)lane);
+        const uint32_t q = (lane * ((65536u + m - 1u) / m)) >> 16;  // lane / m for lane < 64, m <= 32
+        const uint32_t r = lane - q * m;
+        const uint32_t owner = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r << 2), (int)slot_owner);
+        const uint32_t o_pixel = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)pixel);
+        const uint32_t o_sample = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)sample);
+        const uint32_t o_ctr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)ctr);
+        V3 cand;
+        const bool ok = unit_vector_trial(k0, k1, o_pixel, o_sample, o_ctr + 3u * q, cand) && q < per;
+        const unsigned long long accepted = __ballot(ok);
+        uint32_t src = lane, used = per;
+        bool found = false;
+        if (pending) {
+            for (uint32_t t = 0; t < per; ++t) {
+                const uint32_t at = rank + t * m;
+                if (!found && ((accepted >> at) & 1ull)) { found = true; src = at; used = t + 1u; }
+            }
+            ctr += 3u * used;
+        }
+        const double fx = lane_pull(src, cand.x), fy = lane_pull(src, cand.y), fz = lane_pull(src, cand.z);
+        if (found) { p = mk(fx, fy, fz); pending = false; }
+    }
+    return want ? unit(p) : p;
+}
+#elif defined(__HIPCC__)
+__device__ V3 wave_unit_vector(bool want, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t& ctr);
+#endif
 // One draw at position (pixel, sample, ctr) without carrying a cached block around (the tree walk draws at most
 // once per medium and must stay light on registers).
 RT_HD double rng_draw_at(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t ctr) {
@@ -1143,9 +1212,17 @@ RT_HD double reflectance(double cosine, double ri) {  // material.rs:161-166
     double r0s = r0 * r0;
     return r0s + (1.0 - r0s) * pow(1.0 - cosine, 5.0);
 }
+// Whether scatter's first draw is random_unit_vector (Lambertian, Metal, Isotropic; in a plain scene everything
+// but a light).
 template <bool PLAIN = false>
-RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& rec, Rng& rng, V3& out_d, V3& att,
-                   V3& emit) {
+RT_HD bool scatter_wants_unit_vector(const rt_material& m) {
+    if (PLAIN) return m.kind != RT_MAT_DIFFUSE_LIGHT;
+    return m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_ISOTROPIC;
+}
+// scatter with that vector already drawn (`ruv`, and rng past it); see scatter below.
+template <bool PLAIN = false>
+RT_HD bool scatter_given(const DScene& S, const rt_material& m, V3 ray_d, const Rec& rec, Rng& rng, V3 ruv, V3& out_d,
+                         V3& att, V3& emit) {
     emit = mk(0, 0, 0);
     if (PLAIN) {
         // the three materials of a plain scene over solid colours: no checker / image / perlin code, no metal, no
@@ -1153,7 +1230,6 @@ RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& r
         const rt_texture t = S.texs[m.texture];
         const V3 colour = mk(t.color[0], t.color[1], t.color[2]);
         if (m.kind == RT_MAT_DIFFUSE_LIGHT) { emit = colour; return false; }
-        const V3 ruv = random_unit_vector(rng);
         if (m.kind == RT_MAT_LAMBERTIAN) {
             V3 temp = rec.n + ruv;
             out_d = near_zero(temp) ? rec.n : temp;
@@ -1164,13 +1240,11 @@ RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& r
         return true;
     }
     // What several materials share is evaluated once, ahead of the switch, so that a wavefront with a mix of
-    // materials runs the rejection loop and the texture code once instead of once per material.  The random unit
-    // vector is the first (and only) thing Lambertian, Metal and Isotropic draw, so the stream is unchanged.
+    // materials runs the texture code once instead of once per material (and the caller the rejection loop: the
+    // random unit vector is the first and only thing Lambertian, Metal and Isotropic draw).
     const bool wants_tex = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
-    const bool wants_ruv = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_ISOTROPIC;
-    V3 tex = mk(0, 0, 0), ruv = mk(0, 0, 0);
+    V3 tex = mk(0, 0, 0);
     if (wants_tex) tex = tex_value(S, m.texture, rec.u, rec.v, rec.p);
-    if (wants_ruv) ruv = random_unit_vector(rng);
     switch (m.kind) {
         case RT_MAT_LAMBERTIAN: {  // :45-68
             V3 temp = rec.n + ruv;
@@ -1205,6 +1279,13 @@ RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& r
             return true;
         }
     }
+}
+template <bool PLAIN = false>
+RT_HD bool scatter(const DScene& S, const rt_material& m, V3 ray_d, const Rec& rec, Rng& rng, V3& out_d, V3& att,
+                   V3& emit) {
+    V3 ruv = mk(0, 0, 0);
+    if (scatter_wants_unit_vector<PLAIN>(m)) ruv = random_unit_vector(rng);
+    return scatter_given<PLAIN>(S, m, ray_d, rec, rng, ruv, out_d, att, emit);
 }
 
 // Camera::get_ray, camera.rs:479-507.
