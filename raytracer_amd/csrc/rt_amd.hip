@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
 // path's batch index j = s_local * npix + pixel, which k_film_accumulate then adds up in sample order.
 // counters[0] += rays traced, counters[1] = max(deepest bounce).
 template <bool COUNT, int MEDIA, bool PLAIN>
-__global__ void __launch_bounds__(TRAV_BLOCK, 2) k_paths_lockstep(DScene S, rt_camera cam, uint64_t seed, uint32_t npix,
+__global__ void __launch_bounds__(TRAV_BLOCK, (MEDIA == RT_MEDIA_NONE && PLAIN && !COUNT) ? 3 : 2) k_paths_lockstep(DScene S, rt_camera cam, uint64_t seed, uint32_t npix,
                                                                    uint32_t sample0, uint32_t npaths, uint32_t max_depth,
                                                                    double bgr, double bgg, double bgb, double* lum_r,
                                                                    double* lum_g, double* lum_b, uint32_t* work,
@@ -272,34 +272,48 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 2) k_paths_lockstep(DScene S, rt_c
             if (exhausted) break;
             continue;
         }
+        // three stretches entered by whole wavefronts; between them all 64 lanes are back together, which the shared
+        // rejection loop in the middle needs
+        bool hit = false;
+        Rec rec;
+        rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
+        rt_material m;
+        m.kind = RT_MAT_DIFFUSE_LIGHT; m.texture = 0; m.param = 0; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0;
         if (alive) {
             RayVal src; src.o = o; src.d = d;
             Ray w = src.world();
             rays++;
             RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32); rp.pixel = pix; rp.sample = smp; rp.ctr = ctr;
             Best b = closest_hit<COUNT, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
-            V3 lum = mk(0, 0, 0);
+            ctr = rp.ctr;
             if (b.ref == RT_NO_HIT) {
-                lum = beta * mk(bgr, bgg, bgb);
+                const V3 lum = beta * mk(bgr, bgg, bgb);
+                lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z;
                 alive = false;
             } else {
-                Rec rec = finalize<false, PLAIN>(S, w, b);
-                Rng rng = rng_make(seed, pix, smp, rp.ctr);
-                V3 nd, att, emit;
-                const rt_material m = S.mats[rec.mat];
-                if (!scatter<PLAIN>(S, m, w.d, rec, rng, nd, att, emit)) {
-                    lum = beta * emit;
-                    alive = false;
-                } else if (depth + 1u == max_depth) {
-                    alive = false;  // the scattered ray would be traced with depth 0: black (camera.rs:350-352)
-                } else {
-                    beta = beta * att;
-                    o = rec.p;
-                    d = nd;
-                    ctr = rng.ctr;
-                    depth++;
-                    deepest = deepest > depth ? deepest : depth;
-                }
+                rec = finalize<false, PLAIN>(S, w, b);
+                m = S.mats[rec.mat];
+                hit = true;
+            }
+        }
+        const V3 ruv = wave_unit_vector(hit && scatter_wants_unit_vector<PLAIN>(m), (uint32_t)seed, (uint32_t)(seed >> 32),
+                                        pix, smp, ctr);
+        if (hit) {
+            Rng rng = rng_make(seed, pix, smp, ctr);
+            V3 nd, att, emit;
+            V3 lum = mk(0, 0, 0);
+            if (!scatter_given<PLAIN>(S, m, d, rec, rng, ruv, nd, att, emit)) {
+                lum = beta * emit;
+                alive = false;
+            } else if (depth + 1u == max_depth) {
+                alive = false;  // the scattered ray would be traced with depth 0: black (camera.rs:350-352)
+            } else {
+                beta = beta * att;
+                o = rec.p;
+                d = nd;
+                ctr = rng.ctr;
+                depth++;
+                deepest = deepest > depth ? deepest : depth;
             }
             if (!alive) { lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z; }
         }
@@ -352,6 +366,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
     bool alive = false;
     V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
     uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
+    bool hit = false;
+    Rec rec;
+    rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
+    rt_material m;
+    m.kind = RT_MAT_DIFFUSE_LIGHT; m.texture = 0; m.param = 0; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0;
+    V3 wd = mk(0, 0, 0);
     if (idx < n) {
         slot = q.slot[idx];
         born = q.born[idx];
@@ -362,23 +382,31 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         } else {
             pix = q.pix[idx];
             smp = q.smp[idx];
+            ctr = q.ctr[idx];
             Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
             Best b; b.t = hb.t[idx]; b.ref = ref; b.chain = hb.chain[idx];
-            Rec rec = finalize<false, PLAIN>(S, w, b);
-            Rng rng = rng_make(seed, pix, smp, q.ctr[idx]);
-            V3 att, emit;
-            const rt_material m = S.mats[rec.mat];
-            if (!scatter<PLAIN>(S, m, w.d, rec, rng, nd, att, emit)) {
-                lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
-            } else if (iter - born + 1u == max_depth) {
-                // the scattered ray would be traced with depth 0: ray_color returns black (camera.rs:350-352)
-                lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;
-            } else {
-                beta = beta * att;
-                no = rec.p;
-                ctr = rng.ctr;
-                alive = true;
-            }
+            rec = finalize<false, PLAIN>(S, w, b);
+            m = S.mats[rec.mat];
+            wd = w.d;
+            hit = true;
+        }
+    }
+    // all 64 lanes of every wavefront are back together here, which the shared rejection loop needs
+    const V3 ruv = wave_unit_vector(hit && scatter_wants_unit_vector<PLAIN>(m), (uint32_t)seed, (uint32_t)(seed >> 32),
+                                    pix, smp, ctr);
+    if (hit) {
+        Rng rng = rng_make(seed, pix, smp, ctr);
+        V3 att, emit;
+        if (!scatter_given<PLAIN>(S, m, wd, rec, rng, ruv, nd, att, emit)) {
+            lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
+        } else if (iter - born + 1u == max_depth) {
+            // the scattered ray would be traced with depth 0: ray_color returns black (camera.rs:350-352)
+            lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;
+        } else {
+            beta = beta * att;
+            no = rec.p;
+            ctr = rng.ctr;
+            alive = true;
         }
     }
     // compaction: ballot + prefix count per wave, one atomic per workgroup
