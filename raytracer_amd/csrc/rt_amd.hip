@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <numeric>
 #include <vector>
 
 #include "rt_core.h"
@@ -49,6 +50,7 @@ struct Queue {
     uint32_t* slot;                       // where the path's radiance goes in the luminance buffer
     uint32_t* born;                       // iteration the path was generated in (depth = iteration - born)
     uint32_t* ctr;                        // next draw index of the path's random stream
+    uint32_t* sig;                        // ray_signature of the ray (written by k_raygen and k_bounce_lockstep only)
 };
 struct HitBuf {
     double* t;
@@ -61,7 +63,7 @@ extern __shared__ double2 g_levels[];
 // Camera::get_ray (camera.rs:479-492) for one batch of `nsamples` consecutive samples of every pixel, appended to
 // the queue at `base`.  Batch-local path j = s_local * npix + pixel keeps primary rays of neighbouring pixels in
 // neighbouring lanes.
-__global__ void __launch_bounds__(256) k_raygen(rt_camera cam, uint64_t seed, uint32_t npix, uint32_t sample0,
+__global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, rt_camera cam, uint64_t seed, uint32_t npix, uint32_t sample0,
                                                  uint32_t n, uint32_t base, uint32_t slot0, uint32_t iter, Queue q) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -78,6 +80,33 @@ __global__ void __launch_bounds__(256) k_raygen(rt_camera cam, uint64_t seed, ui
     q.slot[idx] = slot0 + j;
     q.born[idx] = iter;
     q.ctr[idx] = rng.ctr;
+    q.sig[idx] = ray_signature(*Gp, o, d);
+}
+
+// The rays of one launch over a tree without BVH entries: up to RT_MAX_SEG stretches of the input queue, each starting
+// a new workgroup.  Rays that go on are sorted by signature class (the low bits of ray_signature) into regions of
+// `out_stride` slots of the output queue, one counter per class, so that the next launch finds rays of one class in
+// the same wavefronts.  nseg = 0: one stretch, slots 0 .. n - 1, one class.
+#define RT_MAX_SEG 5
+#define RT_COUNT_STRIDE 64u  // class counters sit 256 bytes apart: their atomics go to different cache lines
+struct Segs {
+    uint32_t base[RT_MAX_SEG], count[RT_MAX_SEG], block0[RT_MAX_SEG + 1];  // block0[k]: first workgroup of stretch k
+    uint32_t nseg, nclass, out_stride;
+};
+// Queue slot of this thread, or `end` (one past the last slot of its stretch) when it has none.
+__device__ __forceinline__ uint32_t seg_slot(const Segs& segs, uint32_t n, uint32_t& end) {
+    if (segs.nseg == 0u) {
+        end = n;
+        const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+        return idx < n ? idx : n;
+    }
+    uint32_t seg_base = segs.base[0], seg_count = segs.count[0], seg_block0 = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < RT_MAX_SEG; ++k)  // constant indices only: the argument block stays in scalar registers
+        if (k < segs.nseg && blockIdx.x >= segs.block0[k]) { seg_base = segs.base[k]; seg_count = segs.count[k]; seg_block0 = segs.block0[k]; }
+    const uint32_t local = (blockIdx.x - seg_block0) * blockDim.x + threadIdx.x;
+    end = seg_base + seg_count;
+    return local < seg_count ? seg_base + local : end;
 }
 
 // What a traverse launch works on: the queue of rays, where the closest hits go, and -- for caller-supplied batches
@@ -90,6 +119,7 @@ struct TravArgs {
     const double* tmin;     // nullable
     const double* tmax;     // nullable
     uint32_t chunk;         // rays a wavefront of the persistent kernel takes per hand-out
+    Segs segs;              // lockstep kernel: where the rays are
 };
 __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, RngPos& rng, double& tmin, double& tmax) {
     rng.k0 = (uint32_t)a.seed; rng.k1 = (uint32_t)(a.seed >> 32);
@@ -111,16 +141,20 @@ __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long lo
 // ray, all lanes visit the same entries in the same order, scene data comes through scalar loads.
 template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n;
+    const uint32_t idx = seg_slot(a.segs, a.n, n);
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
-    if (idx < a.n) {
+    // with sorted queues the wavefront walks the copy of the tree without everything its rays' signatures rule out
+    uint32_t first = 0u;
+    if (a.segs.nseg != 0u) first = tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
+    if (idx < n) {
         RngPos rng;
         double tmin, tmax;
         trav_ray_setup(a, idx, rng, tmin, tmax);
         RaySoA src;
         src.ox = a.q.ox; src.oy = a.q.oy; src.oz = a.q.oz; src.dx = a.q.dx; src.dy = a.q.dy; src.dz = a.q.dz; src.idx = idx;
-        Best b = closest_hit<COUNT, true, MEDIA>(S, src, tmin, tmax, L, rng, tally);
+        Best b = closest_hit<COUNT, true, MEDIA>(S, src, tmin, tmax, L, rng, tally, first);
         a.hb.t[idx] = b.t; a.hb.ref[idx] = b.ref; a.hb.chain[idx] = b.chain;
         a.q.ctr[idx] = rng.ctr;
     }
@@ -356,13 +390,15 @@ __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
 template <bool PLAIN>
-__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, uint64_t seed, uint32_t n, Queue q, HitBuf hb,
+__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
+                                                       uint32_t n_all, Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
                                                        uint32_t iter, uint32_t max_depth) {
-    __shared__ uint32_t wave_total[SHADE_BLOCK / 64];
-    __shared__ uint32_t block_base;
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t wave_total[SHADE_BLOCK / 64][4];
+    __shared__ uint32_t block_base[4];
+    uint32_t n;
+    const uint32_t idx = seg_slot(segs, n_all, n);
     bool alive = false;
     V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
     uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
@@ -409,25 +445,33 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
             alive = true;
         }
     }
-    // compaction: ballot + prefix count per wave, one atomic per workgroup
-    unsigned long long mask = __ballot(alive);
-    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    // compaction by signature class (one class unless the queues are sorted): ballot + prefix count per wave and
+    // class, one atomic per workgroup and class
+    uint32_t sig = 0xFFFFFFFFu;
+    if (alive) sig = ray_signature(*Gp, no, nd);
+    const uint32_t cls = sig & (segs.nclass - 1u);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t prefix = 0;
+    for (uint32_t c = 0; c < segs.nclass; ++c) {
+        const unsigned long long mask = __ballot(alive && cls == c);
+        if (cls == c) prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_total[wave][c] = (uint32_t)__popcll(mask);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < segs.nclass) {
         uint32_t tot = 0;
-        for (int k = 0; k < SHADE_BLOCK / 64; ++k) { uint32_t c = wave_total[k]; wave_total[k] = tot; tot += c; }
-        block_base = tot ? atomicAdd(out_count, tot) : 0u;
+        for (int k = 0; k < SHADE_BLOCK / 64; ++k) { uint32_t c = wave_total[k][threadIdx.x]; wave_total[k][threadIdx.x] = tot; tot += c; }
+        block_base[threadIdx.x] = tot ? atomicAdd(out_count + RT_COUNT_STRIDE * threadIdx.x, tot) : 0u;
     }
     __syncthreads();
     if (alive) {
-        uint32_t dst = block_base + wave_total[wave] + prefix;
+        uint32_t dst = cls * segs.out_stride + block_base[cls] + wave_total[wave][cls] + prefix;
         out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
         out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
         out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
         out.ctr[dst] = ctr;
+        out.sig[dst] = sig;
     }
 }
 
@@ -437,11 +481,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
 #define BOUNCE_BLOCK 256
 template <int MEDIA, bool PLAIN>
 __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_bounce_lockstep(
-    DScene S, uint64_t seed, uint32_t n, Queue q, Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
+    DScene S, const SigInfo* __restrict__ Gp, uint64_t seed, Segs segs, Queue q, Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
     double* lum_b, double bgr, double bgg, double bgb, uint32_t iter, uint32_t max_depth) {
-    __shared__ uint32_t wave_total[BOUNCE_BLOCK / 64];
-    __shared__ uint32_t block_base;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t wave_total[BOUNCE_BLOCK / 64][4];
+    __shared__ uint32_t block_base[4];
+    uint32_t n;
+    const uint32_t idx = seg_slot(segs, 0u, n);
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     bool alive = false;
@@ -455,20 +500,26 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     rt_material m;
     m.kind = RT_MAT_DIFFUSE_LIGHT; m.texture = 0; m.param = 0; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0;
     V3 wd = mk(0, 0, 0);
+    // the wavefront walks the copy of the tree without everything its rays' signatures rule out
+    const uint32_t first = tree_without(S, sig_skip_mask(idx < n ? q.sig[idx] : 0u));
     if (idx < n) {
         RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32);
         rp.pixel = q.pix[idx]; rp.sample = q.smp[idx]; rp.ctr = q.ctr[idx];
         RaySoA src;
         src.ox = q.ox; src.oy = q.oy; src.oz = q.oz; src.dx = q.dx; src.dy = q.dy; src.dz = q.dz; src.idx = idx;
-        const Best b = closest_hit<false, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
-        slot = q.slot[idx];
-        born = q.born[idx];
-        beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
+        const Best b = closest_hit<false, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally, first);
+        // the rest of the path state is addressed through a copy of idx the compiler cannot see through: otherwise
+        // it forms the addresses (and re-uses the ray loaded above) ahead of the walk and spills them across it
+        uint32_t at = idx;
+        asm volatile("" : "+v"(at));
+        slot = q.slot[at];
+        born = q.born[at];
+        beta = mk(q.br[at], q.bg[at], q.bb[at]);
         pix = rp.pixel; smp = rp.sample; ctr = rp.ctr;
         if (b.ref == RT_NO_HIT) {
             lum_r[slot] = beta.x * bgr; lum_g[slot] = beta.y * bgg; lum_b[slot] = beta.z * bgb;
         } else {
-            Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
+            Ray w = ray_world(mk(q.ox[at], q.oy[at], q.oz[at]), mk(q.dx[at], q.dy[at], q.dz[at]));
             rec = finalize<false, PLAIN>(S, w, b);
             m = S.mats[rec.mat];
             wd = w.d;
@@ -491,24 +542,32 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
             alive = true;
         }
     }
-    unsigned long long mask = __ballot(alive);
-    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    // compaction by signature class: ballot + prefix count per wave and class, one atomic per workgroup and class
+    uint32_t sig = 0xFFFFFFFFu;
+    if (alive) sig = ray_signature(*Gp, no, nd);
+    const uint32_t cls = sig & (segs.nclass - 1u);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t prefix = 0;
+    for (uint32_t c = 0; c < segs.nclass; ++c) {
+        const unsigned long long mask = __ballot(alive && cls == c);
+        if (cls == c) prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_total[wave][c] = (uint32_t)__popcll(mask);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < segs.nclass) {
         uint32_t tot = 0;
-        for (int k = 0; k < BOUNCE_BLOCK / 64; ++k) { uint32_t c = wave_total[k]; wave_total[k] = tot; tot += c; }
-        block_base = tot ? atomicAdd(out_count, tot) : 0u;
+        for (int k = 0; k < BOUNCE_BLOCK / 64; ++k) { uint32_t c = wave_total[k][threadIdx.x]; wave_total[k][threadIdx.x] = tot; tot += c; }
+        block_base[threadIdx.x] = tot ? atomicAdd(out_count + RT_COUNT_STRIDE * threadIdx.x, tot) : 0u;
     }
     __syncthreads();
     if (alive) {
-        uint32_t dst = block_base + wave_total[wave] + prefix;
+        uint32_t dst = cls * segs.out_stride + block_base[cls] + wave_total[wave][cls] + prefix;
         out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
         out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
         out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
         out.ctr[dst] = ctr;
+        out.sig[dst] = sig;
     }
 }
 
@@ -614,10 +673,12 @@ struct rt_scene {
     std::vector<void*> allocs;
     DScene d;
     const uint4* nodes_nocull = nullptr;  // the tree with every cull box infinite (RT_FLAG_NO_CULL)
+    SigInfo sig;                          // what ray signatures are made of (trees without BVH entries)
+    const SigInfo* d_sig = nullptr;       // on the device
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // render workspace, grown on demand
-    size_t ws_paths = 0, ws_lum = 0;
+    size_t ws_paths = 0, ws_lum = 0, ws_hits = 0;
     std::vector<void*> ws_allocs;
     Queue qa, qb;
     HitBuf hb;
@@ -889,7 +950,20 @@ int rt_scene_commit(rt_scene* s, int device) {
     // tree entries as the kernels read them (rt_records.h), and a second copy with every cull box switched off
     {
         const double* cb = s->cull_boxes.empty() ? nullptr : s->cull_boxes.data();
-        std::vector<uint32_t> rec = build_records(s->nodes.data(), s->nodes.size(), s->boxes.data(), cb, true, true);
+        const std::vector<uint32_t> sig = signature_nodes(s->nodes.data(), s->nodes.size(), RT_MAX_SIG);
+        {
+            DScene h;  // host pointers, for ray_in_chain
+            std::memset(&h, 0, sizeof h);
+            h.chains = s->chains.data(); h.ops = s->ops.data();
+            std::memset(&s->sig, 0, sizeof s->sig);
+            s->sig.n = (uint32_t)sig.size();
+            for (size_t b = 0; b < sig.size(); ++b)
+                signature_entry(s->sig, h, (uint32_t)b, s->nodes[sig[b]], s->boxes.data() + 6 * (size_t)s->nodes[sig[b]].first);
+            const std::vector<SigInfo> one(1, s->sig);
+            if ((rc = upload(s, one, &s->d_sig))) return rc;
+        }
+        std::vector<uint32_t> rec = build_record_variants(s->nodes.data(), s->nodes.size(), s->boxes.data(), cb, true, sig);
+        d.n_variants = 1u << sig.size();
         s->media_mode = RT_MEDIA_NONE;
         for (size_t i = 0; i < s->nodes.size(); ++i) {
             if (s->nodes[i].kind != RT_NODE_MEDIUM) continue;
@@ -931,8 +1005,8 @@ int rt_scene_commit(rt_scene* s, int device) {
 #undef UP
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipHostMalloc((void**)&s->h_count, 64, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&s->d_count, 64));
+    HIP_TRY(hipHostMalloc((void**)&s->h_count, 1024, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&s->d_count, 1024));
     s->allocs.push_back(s->d_count);
     HIP_TRY(hipMalloc((void**)&s->d_tallies, 64));
     s->allocs.push_back(s->d_tallies);
@@ -995,11 +1069,11 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 }  // extern "C++"
 
 // One traverse+intersect launch over the rays of `a` on the scene's stream.
-static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocull = false) {
+static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocull = false, uint32_t blocks = 0) {
     const size_t lds = levels_lds(s, TRAV_BLOCK);
     DScene d = s->d;
-    if (nocull) d.nodes = s->nodes_nocull;
-    const uint32_t waves = (a.n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
+    const uint32_t waves = blocks ? blocks : (a.n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     if (!s->has_bvh) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
         if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
@@ -1096,31 +1170,36 @@ static int ws_queue(rt_scene* s, Queue& q, size_t n) {
         HIP_TRY(hipMalloc((void**)pp, n * sizeof(double)));
         s->ws_allocs.push_back(*pp);
     }
-    uint32_t** g[5] = {&q.pix, &q.smp, &q.slot, &q.born, &q.ctr};
+    uint32_t** g[6] = {&q.pix, &q.smp, &q.slot, &q.born, &q.ctr, &q.sig};
     for (auto pp : g) {
         HIP_TRY(hipMalloc((void**)pp, n * sizeof(uint32_t)));
         s->ws_allocs.push_back(*pp);
     }
     return RT_OK;
 }
-static int ensure_workspace(rt_scene* s, size_t paths, size_t lum) {
-    if (s->ws_paths >= paths && s->ws_lum >= lum) return RT_OK;
+static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits) {
+    if (s->ws_paths >= paths && s->ws_lum >= lum && s->ws_hits >= hits) return RT_OK;
     free_list(s->ws_allocs);
     int rc;
     paths = std::max(paths, s->ws_paths);  // what is freed above is allocated again, never less
     lum = std::max(lum, s->ws_lum);
+    hits = std::max(hits, s->ws_hits);
+    s->ws_paths = s->ws_lum = s->ws_hits = 0;
     if (paths) {
         if ((rc = ws_queue(s, s->qa, paths))) return rc;
         if ((rc = ws_queue(s, s->qb, paths))) return rc;
-        HIP_TRY(hipMalloc((void**)&s->hb.t, paths * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
-        HIP_TRY(hipMalloc((void**)&s->hb.ref, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
-        HIP_TRY(hipMalloc((void**)&s->hb.chain, paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
+    }
+    if (hits) {
+        HIP_TRY(hipMalloc((void**)&s->hb.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
+        HIP_TRY(hipMalloc((void**)&s->hb.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
+        HIP_TRY(hipMalloc((void**)&s->hb.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
     }
     HIP_TRY(hipMalloc((void**)&s->lum_r, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
     HIP_TRY(hipMalloc((void**)&s->lum_g, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
     HIP_TRY(hipMalloc((void**)&s->lum_b, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
     s->ws_paths = paths;
     s->ws_lum = lum;
+    s->ws_hits = hits;
     return RT_OK;
 }
 
@@ -1167,7 +1246,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         const uint32_t spb = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, budget / npix), o->spp_count);
         const uint64_t bsize = (uint64_t)spb * npix;
         if (bsize > 0xFFFFFFFFull - RT_CHUNK * 0x10000ull) return fail(RT_ERR_LIMIT, "batch too large");
-        if ((rc = ensure_workspace(s, 0, (size_t)bsize))) return rc;
+        if ((rc = ensure_workspace(s, 0, (size_t)bsize, 0))) return rc;
         const uint32_t nbatches = (o->spp_count + spb - 1) / spb;
         HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));  // rays traced, deepest bounce
         const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
@@ -1214,44 +1293,76 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         st.rays = h[0];
         st.bounces = (uint32_t)h[1] + 1u;
     } else if (o->max_depth > 0 && o->spp_count > 0) {
-        const uint64_t qcap_want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (32ull << 20), npix);
-        uint32_t spb = (uint32_t)std::max<uint64_t>(1, (qcap_want / 4) / npix);  // samples per batch
+        const uint64_t want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (32ull << 20), npix);
+        uint32_t spb = (uint32_t)std::max<uint64_t>(1, (want / 4) / npix);  // samples per batch
         spb = std::min(spb, o->spp_count);
         const uint64_t bsize = (uint64_t)spb * npix;                      // paths per full batch
-        const uint64_t qcap = std::max<uint64_t>(qcap_want, bsize);
+        // no queue larger than the paths this call traces
+        const uint64_t qcap = std::max<uint64_t>(std::min<uint64_t>(want, (uint64_t)npix * o->spp_count), bsize);
         const uint32_t nbatches = (o->spp_count + spb - 1) / spb;
         const uint32_t nslots = std::min<uint32_t>(o->max_depth + 1u, nbatches);
-        if (qcap > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
-        if ((rc = ensure_workspace(s, (size_t)qcap, (size_t)(bsize * nslots)))) return rc;
+        // Trees without BVH entries: rays that go on are sorted by signature class, one region of qcap slots per
+        // class, and new camera rays go to a region of their own behind those.  One bounce is one kernel (walk, shade
+        // and compaction together) or, on request and in counting passes (those kernels carry the counters), a
+        // traverse and a shade launch.
+        const bool sorted = !s->has_bvh;
+        const bool bounce = sorted && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
+        const uint32_t nclass = sorted ? 1u << s->sig.n : 1u;
+        const uint64_t rows = sorted ? (uint64_t)nclass * qcap + bsize : qcap;
+        if (rows > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
+        if ((rc = ensure_workspace(s, (size_t)rows, (size_t)(bsize * nslots), bounce ? 0 : (size_t)rows))) return rc;
         std::vector<uint32_t> born_at(nbatches, 0);
-        // counting passes go through the separate kernels, which carry the counters
-        const bool bounce = !s->has_bvh && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
         Queue qin = s->qa, qout = s->qb;
         uint32_t n = 0, iter = 0, injected = 0, accumulated = 0;
+        uint32_t in_class[4] = {0, 0, 0, 0};  // rays waiting in each class region of qin (bounce kernel)
         auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
         for (;;) {
+            uint32_t fresh = 0;  // camera rays generated in this iteration
             if (injected < nbatches && (uint64_t)n + bsize <= qcap) {
                 // a slot is reused only after its previous batch has been added to the film
                 if (injected >= nslots && accumulated + nslots <= injected) return fail(RT_ERR_STATE, "luminance slot still in use");
                 const uint32_t ns = batch_samples(injected), nb = ns * npix;
                 const uint32_t slot0 = (uint32_t)((injected % nslots) * bsize);
-                hipLaunchKernelGGL(k_raygen, dim3((nb + 255u) / 256u), dim3(256), 0, sm, *cam, o->seed, npix,
-                                   o->spp_begin + injected * spb, nb, n, slot0, iter, qin);
+                hipLaunchKernelGGL(k_raygen, dim3((nb + 255u) / 256u), dim3(256), 0, sm, s->d_sig, *cam, o->seed, npix,
+                                   o->spp_begin + injected * spb, nb, sorted ? nclass * (uint32_t)qcap : n, slot0, iter, qin);
                 born_at[injected] = iter;
                 injected++;
                 n += nb;
+                fresh = nb;
                 st.paths += nb;
             }
             if (n == 0) break;  // nothing in flight and nothing left to inject
             st.rays += n;
-            HIP_TRY(hipMemsetAsync(s->d_count, 0, 4, sm));
+            HIP_TRY(hipMemsetAsync(s->d_count, 0, 1024, sm));
             HIP_TRY(hipEventRecord(s->ev[1], sm));
+            // where this launch's rays are, for workgroups of `bs` threads
+            auto make_segs = [&](uint32_t bs, uint32_t& blocks) {
+                Segs segs;
+                std::memset(&segs, 0, sizeof segs);
+                segs.nclass = nclass;
+                segs.out_stride = (uint32_t)qcap;
+                blocks = (n + bs - 1) / bs;
+                if (!sorted) return segs;
+                blocks = 0;
+                auto add_seg = [&](uint32_t base, uint32_t cnt) {
+                    if (!cnt) return;
+                    segs.base[segs.nseg] = base; segs.count[segs.nseg] = cnt; segs.block0[segs.nseg] = blocks;
+                    blocks += (cnt + bs - 1) / bs;
+                    segs.block0[++segs.nseg] = blocks;
+                };
+                for (uint32_t c = 0; c < nclass; ++c) add_seg(c * (uint32_t)qcap, in_class[c]);
+                add_seg(nclass * (uint32_t)qcap, fresh);
+                return segs;
+            };
+            const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
             if (bounce) {
                 DScene d = s->d;
-                if (o->flags & RT_FLAG_NO_CULL) d.nodes = s->nodes_nocull;
-#define BOUNCE_ARGS d, o->seed, n, qin, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
+                if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
+                uint32_t blocks = 0;
+                const Segs segs = make_segs(BOUNCE_BLOCK, blocks);
+#define BOUNCE_ARGS d, s->d_sig, o->seed, segs, qin, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
                     o->background[1], o->background[2], iter, o->max_depth
-#define BOUNCE(M, P) hipLaunchKernelGGL((k_bounce_lockstep<M, P>), dim3((n + BOUNCE_BLOCK - 1) / BOUNCE_BLOCK), dim3(BOUNCE_BLOCK), \
+#define BOUNCE(M, P) hipLaunchKernelGGL((k_bounce_lockstep<M, P>), dim3(blocks), dim3(BOUNCE_BLOCK), \
                                         levels_lds(s, BOUNCE_BLOCK), sm, BOUNCE_ARGS)
                 if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) BOUNCE(RT_MEDIA_NONE, true); else BOUNCE(RT_MEDIA_NONE, false); }
                 else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) BOUNCE(RT_MEDIA_FLAT, true); else BOUNCE(RT_MEDIA_FLAT, false); }
@@ -1260,19 +1371,22 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
 #undef BOUNCE_ARGS
                 HIP_TRY(hipEventRecord(s->ev[2], sm));
             } else {
-            TravArgs ta;
-            std::memset(&ta, 0, sizeof ta);
-            ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.n = n;
-            if ((rc = launch_traverse(s, ta, count, (o->flags & RT_FLAG_NO_CULL) != 0))) return rc;
-            HIP_TRY(hipEventRecord(s->ev[2], sm));
-#define SHADE_ARGS s->d, o->seed, n, qin, s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
+                TravArgs ta;
+                std::memset(&ta, 0, sizeof ta);
+                ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.n = n;
+                uint32_t tblocks = 0, sblocks = 0;
+                ta.segs = make_segs(TRAV_BLOCK, tblocks);
+                if ((rc = launch_traverse(s, ta, count, nocull, tblocks))) return rc;
+                HIP_TRY(hipEventRecord(s->ev[2], sm));
+                const Segs ssegs = make_segs(SHADE_BLOCK, sblocks);
+#define SHADE_ARGS s->d, s->d_sig, o->seed, n, ssegs, qin, s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
                    o->background[1], o->background[2], iter, o->max_depth
-            if (s->plain) hipLaunchKernelGGL(k_shade<true>, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
-            else hipLaunchKernelGGL(k_shade<false>, dim3((n + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+                if (s->plain) hipLaunchKernelGGL(k_shade<true>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+                else hipLaunchKernelGGL(k_shade<false>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
 #undef SHADE_ARGS
             }
             HIP_TRY(hipEventRecord(s->ev[3], sm));
-            HIP_TRY(hipMemcpyAsync(s->h_count, s->d_count, 4, hipMemcpyDeviceToHost, sm));
+            HIP_TRY(hipMemcpyAsync(s->h_count, s->d_count, 1024, hipMemcpyDeviceToHost, sm));
             HIP_TRY(hipStreamSynchronize(sm));
             HIP_TRY(hipGetLastError());
             float ms = 0;
@@ -1286,7 +1400,8 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                 st.ms_shade += ms;
                 st.traverse_launches++;
             }
-            n = *s->h_count;
+            n = 0;
+            for (uint32_t c = 0; c < nclass; ++c) { in_class[c] = s->h_count[RT_COUNT_STRIDE * c]; n += in_class[c]; }
             std::swap(qin, qout);
             iter++;
             // batches whose paths are all finished go to the film, oldest first

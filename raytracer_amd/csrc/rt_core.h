@@ -210,6 +210,15 @@ struct RngPos {  // what the walk needs of a path's random stream
 // Scene as the kernels see it: per-type arrays of packed f64 records plus the flattened tree.  Every record array
 // starts 16-byte aligned and every record is a whole number of 16-byte pairs, so records are fetched as double2
 // (one 16-byte load per pair; a quad or triangle is exactly one 128-byte line).
+#define RT_MAX_SIG 2u
+// The CULL entries a ray's signature covers (lockstep trees only), passed to the kernels that compute signatures as an
+// argument of its own so that everything in it arrives in scalar registers.
+struct SigInfo {
+    uint32_t n;         // 0..RT_MAX_SIG
+    double box[2][6];   // the entry's box (x, y, z: start, end)
+    double xf[2][12];   // the map from world space into the entry's chain, p -> A p + b (A row-major in [0..8], b in
+                        // [9..11]; directions take A alone); composed on the host, which a signature's tolerance allows
+};
 struct DScene {
     const uint4* nodes;      // 128 bytes (one cache line) per tree entry: rt_node header | box of a BVH or CULL entry
                              // (3 x double2) | conservative cull box of a BVH entry (3 x double2) | 16 bytes unused
@@ -221,6 +230,10 @@ struct DScene {
     const uint32_t* sphere_mat; const uint32_t* sphere_id;
     const uint32_t* quad_mat;   const uint32_t* quad_id;
     const uint32_t* quad_axis;  // per quad: 1 + the axis its normal lies along when n and w are zero elsewhere, else 0
+    uint32_t n_variants;        // copies of the tree in `nodes` (1, 2 or 4), n_nodes entries each: copy m is the tree
+                                // without the subtrees of the signature entries in mask m (a pruned CULL entry has
+                                // count 1 and the lockstep walk passes its subtree over); indices in copy m count
+                                // from m * n_nodes
     const uint32_t* tri_mat;    const uint32_t* tri_id;
     const uint32_t* quadric_mat; const uint32_t* quadric_id;
     const rt_medium* media;
@@ -588,6 +601,68 @@ RT_HD bool cull_pass(const DScene& S, uint32_t i, uint32_t at, Ray& cur, double 
     return slab(reinterpret_cast<const double2*>(S.nodes + 8u * i + at), cur, s, e);
 }
 
+// A ray's signature: bit b is clear when the LINE the ray lies on cannot touch the cull box of the tree's b-th
+// signature entry, whatever interval the walk arrives there with.  The lockstep walk, where one
+// wavefront visits every entry for all of its lanes, walks a copy of the tree without the entries no lane's signature
+// has the bit of; the scheduler groups rays of equal signature into the same wavefronts so that this happens often.
+RT_HD bool line_off_axis(double mi, double mj, double di, double dj, double hi, double hj) {
+    // separating axis d x e_k, (i, j) the two other coordinates: |m x d|_k against the box's reach along it, with
+    // slack far above the rounding of the products and far below the margin the cull boxes are widened by
+    const double a = mi * dj, b = mj * di;
+    return fabs(a - b) > (hi * fabs(dj) + hj * fabs(di)) * (1.0 + 1e-9) + 1e-9 * (fabs(a) + fabs(b));
+}
+RT_HD uint32_t ray_signature(const SigInfo& G, V3 o, V3 d) {
+    uint32_t sig = 0xFFFFFFFFu;
+    const Ray w = ray_world(o, d);
+#pragma unroll
+    for (uint32_t b = 0; b < RT_MAX_SIG; ++b) {
+        if (b >= G.n) break;
+        const double* A = G.xf[b];
+        Ray c;
+        c.o = mk(A[0] * w.o.x + A[1] * w.o.y + A[2] * w.o.z + A[9], A[3] * w.o.x + A[4] * w.o.y + A[5] * w.o.z + A[10],
+                 A[6] * w.o.x + A[7] * w.o.y + A[8] * w.o.z + A[11]);
+        c.d = mk(A[0] * w.d.x + A[1] * w.d.y + A[2] * w.d.z, A[3] * w.d.x + A[4] * w.d.y + A[5] * w.d.z,
+                 A[6] * w.d.x + A[7] * w.d.y + A[8] * w.d.z);
+        double2 bx, by, bz;
+        bx.x = G.box[b][0]; bx.y = G.box[b][1]; by.x = G.box[b][2]; by.y = G.box[b][3];
+        bz.x = G.box[b][4]; bz.y = G.box[b][5];
+        // line against box without a division: a line misses a box exactly when one of the axes d x e_k separates
+        // them (or, with d_k = 0, the box's own axis e_k does)
+        const V3 h = mk(0.5 * (bx.y - bx.x), 0.5 * (by.y - by.x), 0.5 * (bz.y - bz.x));
+        const V3 m = mk(c.o.x - 0.5 * (bx.x + bx.y), c.o.y - 0.5 * (by.x + by.y), c.o.z - 0.5 * (bz.x + bz.y));
+        const bool off = line_off_axis(m.y, m.z, c.d.y, c.d.z, h.y, h.z) || line_off_axis(m.z, m.x, c.d.z, c.d.x, h.z, h.x) ||
+                         line_off_axis(m.x, m.y, c.d.x, c.d.y, h.x, h.y) || (c.d.x == 0.0 && fabs(m.x) > h.x * (1.0 + 1e-9)) ||
+                         (c.d.y == 0.0 && fabs(m.y) > h.y * (1.0 + 1e-9)) || (c.d.z == 0.0 && fabs(m.z) > h.z * (1.0 + 1e-9));
+        // anything out of the ordinary (infinite box, NaN) compares false above and keeps the bit
+        if (off) sig &= ~(1u << b);
+    }
+    return sig;
+}
+// Host side: entry b of the signature from tree entry `n` (a CULL entry), its box, and the scene's chains / ops.
+inline void signature_entry(SigInfo& G, const DScene& S, uint32_t b, const rt_node& n, const double* box6) {
+    for (int k = 0; k < 6; ++k) G.box[b][k] = box6[k];
+    const V3 e[4] = {mk(0, 0, 0), mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
+    V3 img[4];
+    for (int k = 0; k < 4; ++k) img[k] = ray_in_chain(S, ray_world(e[k], mk(0, 0, 1)), n.chain).o;
+    for (int k = 0; k < 3; ++k) {
+        const V3 col = img[k + 1] - img[0];
+        G.xf[b][0 + k] = col.x; G.xf[b][3 + k] = col.y; G.xf[b][6 + k] = col.z;
+    }
+    G.xf[b][9] = img[0].x; G.xf[b][10] = img[0].y; G.xf[b][11] = img[0].z;
+}
+// What a wavefront of the lockstep walk may pass over: bit b set when no lane's signature has bit b (`sig` of a lane
+// without a ray: 0).  The same value in every lane.
+RT_HD uint32_t sig_skip_mask(uint32_t sig) {
+    uint32_t m = 0u;
+    for (uint32_t b = 0; b < RT_MAX_SIG; ++b)
+        if (wave_all(((sig >> b) & 1u) == 0u)) m |= 1u << b;
+    return wave_first(m);
+}
+// Where the copy of the tree starts that a wavefront with that mask walks.
+RT_HD uint32_t tree_without(const DScene& S, uint32_t skip_mask) {
+    return (skip_mask & (S.n_variants - 1u)) * S.n_nodes;
+}
+
 // BVHNode::hit's box test (bvh.rs:31-37) for the entry `n` at index i: returns the index to go on with.
 template <bool COUNT>
 RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels& L, const Best& best, Ray& cur,
@@ -678,10 +753,10 @@ RT_HD bool boundary_scan(const DScene& S, const Src& src, uint32_t i, const Node
     uint32_t tests = 0, bytes = 0, flops = 0;
     for (uint32_t j = i + 1u; j < n.skip;) {
         const Node r = load_node(S, LOCKSTEP ? wave_first(j) : j);
+        if (LOCKSTEP && r.kind == RT_NODE_CULL) { j = j + 1u; continue; }  // (a medium pruned as a whole never gets here)
         if (r.chain != cur_chain) { cur = ray_in_chain(S, src.world(), r.chain); cur_chain = r.chain; }
         if (r.kind == RT_NODE_CULL) {
-            if (LOCKSTEP) j = j + 1u;
-            else j = cull_pass<COUNT && !SECOND>(S, j, 1u, cur, -RT_INF, RT_INF, tally) ? j + 1u : r.skip;
+            j = cull_pass<COUNT && !SECOND>(S, j, 1u, cur, -RT_INF, RT_INF, tally) ? j + 1u : r.skip;
             continue;
         }
         const uint32_t last = r.first + r.count;
@@ -810,7 +885,7 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
         const double2 iv = lv_get(L, n.level);
         const double s = iv.x, e = fmin(iv.y, best.t);
         if (n.kind == RT_NODE_CULL) {
-            if (LOCKSTEP) i = i + 1u;
+            if (LOCKSTEP) i = n.count != 0u ? n.skip : i + 1u;
             else i = cull_pass<COUNT>(S, i, 1u, cur, s, e, tally) ? i + 1u : n.skip;
         } else if (n.kind == RT_NODE_MEDIUM) {
             if constexpr (MEDIA != RT_MEDIA_NONE) {
@@ -855,12 +930,12 @@ RT_HD void walk(const DScene& S, const Src& src, uint32_t i, uint32_t iend, cons
 // world.hit(ray, tmin..tmax) (camera.rs:363): returns the closest hit as (t, ref, chain).
 template <bool COUNT, bool LOCKSTEP, int MEDIA = RT_MEDIA_ANY, class Src>
 RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax, const Levels& L, RngPos& rng,
-                       Tally& tally) {
+                       Tally& tally, uint32_t first = 0u) {
     Best best; best.t = RT_INF; best.ref = RT_NO_HIT; best.chain = 0;
     lv_set(L, 0u, tmin, tmax);
     Ray cur = src.world();
     uint32_t cur_chain = 0;
-    walk<MEDIA, COUNT, LOCKSTEP>(S, src, 0u, S.n_nodes, L, rng, best, cur, cur_chain, tally);
+    walk<MEDIA, COUNT, LOCKSTEP>(S, src, first, first + S.n_nodes, L, rng, best, cur, cur_chain, tally);
     return best;
 }
 

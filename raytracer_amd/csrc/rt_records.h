@@ -2,6 +2,8 @@
 //
 //   bytes   0..15   rt_node header; a MEDIUM entry's `count` becomes 1 when its boundary is nothing but spheres,
 //                   quads and triangles (the walk then finds both boundary hits in one pass)
+//                   a CULL entry's `count` is 1 when it is a signature entry (see signature_nodes) in `pruned`: the
+//                   lockstep walk passes it over; a medium with nothing but such an entry becomes one itself
 //   bytes  16..63   BVH entry: the reference's box (3 x (start, end)); CULL entry: its box
 //   bytes  64..111  BVH entry: conservative cull box (infinite when the caller supplied none)
 //   bytes 112..127  BVH entry whose subtree is exactly one run of primitives in the same chain (a leaf, the usual
@@ -23,14 +25,23 @@
 namespace rt {
 
 inline std::vector<uint32_t> build_records(const rt_node* nodes, size_t n_nodes, const double* boxes,
-                                           const double* cull_boxes, bool cull, bool one_pass_media) {
+                                           const double* cull_boxes, bool cull, bool one_pass_media,
+                                           const std::vector<uint32_t>& sig_nodes = {}, uint32_t pruned = 0u,
+                                           uint32_t index_base = 0u) {
     const double inf = std::numeric_limits<double>::infinity();
     const double everything[6] = {-inf, inf, -inf, inf, -inf, inf};
     std::vector<uint32_t> rec(32 * n_nodes, 0u);
     for (size_t i = 0; i < n_nodes; ++i) {
         rt_node n = nodes[i];
         uint32_t* r = &rec[32 * i];
-        if (n.kind == RT_NODE_MEDIUM) {
+        bool boundary_pruned = false;  // a medium whose whole boundary lies under a pruned entry goes with it
+        if (n.kind == RT_NODE_MEDIUM && cull && i + 1 < n_nodes && nodes[i + 1].kind == RT_NODE_CULL && nodes[i + 1].skip == n.skip)
+            for (size_t b = 0; b < sig_nodes.size(); ++b)
+                if (sig_nodes[b] == i + 1 && ((pruned >> b) & 1u)) boundary_pruned = true;
+        if (boundary_pruned) {
+            n.kind = RT_NODE_CULL;
+            n.count = 1u;
+        } else if (n.kind == RT_NODE_MEDIUM) {
             bool flat = one_pass_media;
             for (uint32_t j = (uint32_t)i + 1u; j < n.skip; ++j) {
                 const uint8_t k = nodes[j].kind;
@@ -48,11 +59,50 @@ inline std::vector<uint32_t> build_records(const rt_node* nodes, size_t n_nodes,
             }
         } else if (n.kind == RT_NODE_CULL) {
             std::memcpy(r + 4, cull ? boxes + 6 * (size_t)n.first : everything, 48);
-            if (!cull) n.skip = (uint32_t)i + 1u;
+            n.count = 0u;
+            for (size_t b = 0; cull && b < sig_nodes.size(); ++b)
+                if (sig_nodes[b] == i && ((pruned >> b) & 1u)) n.count = 1u;  // the lockstep walk passes it over
+            if (!cull) n.skip = (uint32_t)i + 1u;  // (index_base is added below)
         }
+        n.skip += index_base;  // every index in the record counts from where this copy of the tree starts
         std::memcpy(r, &n, sizeof(rt_node));
     }
     return rec;
+}
+
+// The CULL entries a ray's signature covers, for a tree without BVH entries (the lockstep walk): the first `max_sig`
+// in tree order of those the walk itself meets (not inside another one, not inside a medium's boundary) and those
+// that hold a medium's whole boundary.  Empty for any other tree.
+inline std::vector<uint32_t> signature_nodes(const rt_node* nodes, size_t n_nodes, size_t max_sig) {
+    std::vector<uint32_t> out;
+    for (size_t i = 0; i < n_nodes; ++i)
+        if (nodes[i].kind == RT_NODE_BVH) return out;
+    for (size_t i = 0; i < n_nodes && out.size() < max_sig;) {
+        if (nodes[i].kind == RT_NODE_CULL) {
+            out.push_back((uint32_t)i);
+            i = nodes[i].skip;
+        } else if (nodes[i].kind == RT_NODE_MEDIUM) {
+            if (i + 1 < n_nodes && nodes[i + 1].kind == RT_NODE_CULL && nodes[i + 1].skip == nodes[i].skip)
+                out.push_back((uint32_t)i + 1u);
+            i = nodes[i].skip;
+        } else {
+            ++i;
+        }
+    }
+    return out;
+}
+
+// Every copy of the tree the lockstep walk chooses from, one after the other: copy m lacks the signature entries in m.
+inline std::vector<uint32_t> build_record_variants(const rt_node* nodes, size_t n_nodes, const double* boxes,
+                                                   const double* cull_boxes, bool one_pass_media,
+                                                   const std::vector<uint32_t>& sig_nodes) {
+    std::vector<uint32_t> all;
+    for (uint32_t m = 0; m < (1u << sig_nodes.size()); ++m) {
+        const std::vector<uint32_t> v = build_records(nodes, n_nodes, boxes, cull_boxes, true, one_pass_media, sig_nodes, m,
+                                                      m * (uint32_t)n_nodes);
+        all.insert(all.end(), v.begin(), v.end());
+    }
+    return all;
 }
 
 // Per quad (16 f64: n d q u v w): 1 + the coordinate axis its normal lies along when n and w are exactly zero in the

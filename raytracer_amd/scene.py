@@ -18,7 +18,7 @@ def _opts(spp_begin, spp_count, max_depth, seed, background, batch_paths=0, flag
 
 def _flags(counters, cull, whole_paths, split_bounce=False):
     """whole_paths: None = the library's choice, True / False = force one kernel per batch / the queue schedule;
-    split_bounce: separate traverse and shade launches where the queue schedule would use one bounce kernel."""
+    split_bounce: a traverse and a shade launch per bounce where the queue schedule would use one bounce kernel."""
     return ((_lib.RT_FLAG_COUNTERS if counters else 0) | (0 if cull else _lib.RT_FLAG_NO_CULL) |
             (0 if whole_paths is None else (_lib.RT_FLAG_WHOLE_PATHS if whole_paths else _lib.RT_FLAG_QUEUES)) |
             (_lib.RT_FLAG_SPLIT_BOUNCE if split_bounce else 0))
@@ -74,7 +74,7 @@ class Scene:
         cull boxes off: the same film from exactly the box and primitive tests the reference performs.
         whole_paths=True traces whole paths in one kernel (scenes without BVH entries only), False forces the
         queue-based schedule, None leaves the choice to the library; split_bounce=True makes the queue-based schedule
-        of a scene without BVH entries use separate traverse and shade launches instead of its one bounce kernel."""
+        of a scene without BVH entries use a traverse and a shade launch per bounce instead of its one bounce kernel."""
         film = np.zeros((cam.height, cam.width, 3))
         st = rt_stats()
         o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths, split_bounce))

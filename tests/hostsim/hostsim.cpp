@@ -25,9 +25,19 @@ struct sim_scene {  // host pointers to the arrays of a flattened scene
 static std::vector<uint32_t> g_records, g_quad_axis;
 static int use_cull = 1;      // 0: every cull box switched off, as under RT_FLAG_NO_CULL
 static int use_one_pass = 1;  // 0: media always take their two boundary hits in two passes
+static SigInfo g_sig;
 static DScene to_dscene(const sim_scene* s) {
     DScene d;
-    g_records = build_records(s->nodes, (size_t)s->n_nodes, s->boxes, s->cull_boxes, use_cull != 0, use_one_pass != 0);
+    const std::vector<uint32_t> sig = signature_nodes(s->nodes, (size_t)s->n_nodes, RT_MAX_SIG);
+    if (use_cull) {
+        g_records = build_record_variants(s->nodes, (size_t)s->n_nodes, s->boxes, s->cull_boxes, use_one_pass != 0, sig);
+        d.n_variants = 1u << sig.size();
+    } else {
+        g_records = build_records(s->nodes, (size_t)s->n_nodes, s->boxes, s->cull_boxes, false, use_one_pass != 0);
+        d.n_variants = 1u;
+    }
+    std::memset(&g_sig, 0, sizeof g_sig);
+    g_sig.n = (uint32_t)sig.size();
     d.nodes = reinterpret_cast<const uint4*>(g_records.data()); d.n_nodes = (uint32_t)s->n_nodes; d.spheres = s->spheres; d.quads = s->quads;
     d.tris = s->tris; d.quadrics = s->quadrics; d.sphere_mat = s->sphere_mat; d.sphere_id = s->sphere_id;
     d.quad_mat = s->quad_mat; d.quad_id = s->quad_id; d.tri_mat = s->tri_mat; d.tri_id = s->tri_id;
@@ -37,6 +47,7 @@ static DScene to_dscene(const sim_scene* s) {
     g_quad_axis = quad_axis_flags(s->quads, (size_t)s->n_quads);
     g_quad_axis.push_back(0u);
     d.quad_axis = g_quad_axis.data();
+    for (size_t b = 0; b < sig.size(); ++b) signature_entry(g_sig, d, (uint32_t)b, s->nodes[sig[b]], s->boxes + 6 * (size_t)s->nodes[sig[b]].first);
     return d;
 }
 
@@ -45,6 +56,8 @@ extern "C" void sim_set_uniform_mode(int on) { host_uniform_mode() = on != 0; }
 extern "C" void sim_set_walk_mode(int m) { mode = m; }
 extern "C" void sim_set_cull(int on) { use_cull = on; }
 extern "C" void sim_set_one_pass(int on) { use_one_pass = on; }
+static int use_sig = 1;  // lockstep walk: 0 leaves every ray's signature at all ones (nothing is passed over)
+extern "C" void sim_set_signatures(int on) { use_sig = on; }
 extern "C" unsigned long long sim_fallbacks(void) { return host_fallback_count(); }
 
 extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o3, const double* d3, const double* tmin,
@@ -61,6 +74,8 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
         rng.pixel = rng3 ? rng3[3 * i] : (uint32_t)i; rng.sample = rng3 ? rng3[3 * i + 1] : 0u; rng.ctr = rng3 ? rng3[3 * i + 2] : 0u;
         RayAoS src; src.o3 = o3; src.d3 = d3; src.i = i;
         Ray w = src.world();
+        uint32_t first = 0;  // a "wavefront" of one lane walks the tree without everything its signature rules out
+        if (mode == 1 && use_sig) first = tree_without(S, sig_skip_mask(ray_signature(g_sig, w.o, w.d)));
         Best b;
         if (mode == 2) {  // the per-lane state machine of the persistent kernel
             Lane ln;
@@ -73,7 +88,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
             }
             b = ln.best;
         } else if (mode == 1) {
-            b = closest_hit<true, true>(S, src, tmin[i], tmax[i], L, rng, tally);
+            b = closest_hit<true, true>(S, src, tmin[i], tmax[i], L, rng, tally, first);
         } else {
             b = closest_hit<true, false>(S, src, tmin[i], tmax[i], L, rng, tally);
         }

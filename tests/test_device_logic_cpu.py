@@ -76,6 +76,29 @@ def test_cull_boxes_save_work(pairs, cfg):
         assert with_cull["prim_tests"] < 0.7 * base["prim_tests"]
 
 
+def test_ray_signatures_prune_the_lockstep_walk(pairs):
+    """A lockstep wavefront whose rays all have a signature bit clear walks a copy of the tree without that
+    entry's subtree (here: a "wavefront" of one ray).  Same hits as the oracle, and on cornell_smoke, whose two
+    media are the signature entries, far fewer boundary tests than with the signatures left at all ones."""
+    hs, os_, sim = pairs("C2")
+    L = helpers._sim_lib()
+    _, oc = cameras(hs)
+    o, d, rng3 = path_rays(os_, oc, 1500, 1)
+    want = os_.builder.intersect(o, d, 0.001, np.inf, rng3)
+    L.sim_set_walk_mode(1)
+    try:
+        got = sim.intersect(o, d, 0.001, np.inf, rng3)
+        L.sim_set_signatures(0)
+        plain = sim.intersect(o, d, 0.001, np.inf, rng3)
+    finally:
+        L.sim_set_signatures(1)
+        L.sim_set_walk_mode(0)
+    assert_hits_equal(got, want, exact=True, what="with signatures")
+    assert_hits_equal(plain, want, exact=True, what="without signatures")
+    assert plain["counters"]["prim_tests"] == want["counters"]["prim_tests"]
+    assert got["counters"]["prim_tests"] < 0.6 * plain["counters"]["prim_tests"]
+
+
 @pytest.mark.parametrize("cfg", CONFIGS)
 def test_arbitrary_intervals_and_directions(pairs, cfg):
     """Rays that do not come from the camera: random origins inside the scene's extent, random directions, random

@@ -94,8 +94,8 @@ def test_per_sample_radiance_matches_oracle(gpu_scenes, cfg):
 def test_film_equals_sum_of_samples(gpu_scenes, cfg, schedule):
     """rt_render must give, bit for bit, the in-order sum of the per-sample radiances rt_trace_samples computes with
     one lane per whole path -- on every schedule: the queue-based one (queues + compaction + film accumulation; for
-    scenes without BVH entries with one bounce kernel or, on request, with separate traverse and shade launches)
-    and whole paths in one kernel (on request, for scenes without BVH entries)."""
+    scenes without BVH entries with queues sorted by ray signature and one kernel per bounce or, on request, a
+    traverse and a shade launch) and whole paths in one kernel (on request, for scenes without BVH entries)."""
     hs, os_, scene = gpu_scenes(cfg)
     hc, _ = cameras(hs)
     spp = 3
