@@ -508,10 +508,11 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
         RaySoA src;
         src.ox = q.ox; src.oy = q.oy; src.oz = q.oz; src.dx = q.dx; src.dy = q.dy; src.dz = q.dz; src.idx = idx;
         const Best b = closest_hit<false, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally, first);
-        // the rest of the path state is addressed through a copy of idx the compiler cannot see through: otherwise
-        // it forms the addresses (and re-uses the ray loaded above) ahead of the walk and spills them across it
+        // With full materials the rest of the path state is addressed through a copy of idx the compiler cannot see
+        // through: otherwise it forms the addresses (and re-uses the ray loaded above) ahead of the walk and spills
+        // them across it.  The plain-material kernel has the registers to spare and gains from the early loads.
         uint32_t at = idx;
-        asm volatile("" : "+v"(at));
+        if (!PLAIN) asm volatile("" : "+v"(at));
         slot = q.slot[at];
         born = q.born[at];
         beta = mk(q.br[at], q.bg[at], q.bb[at]);
