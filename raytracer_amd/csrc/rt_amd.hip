@@ -83,30 +83,52 @@ __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, 
     q.sig[idx] = ray_signature(*Gp, o, d);
 }
 
-// The rays of one launch over a tree without BVH entries: up to RT_MAX_SEG stretches of the input queue, each starting
-// a new workgroup.  Rays that go on are sorted by signature class (the low bits of ray_signature) into regions of
-// `out_stride` slots of the output queue, one counter per class, so that the next launch finds rays of one class in
-// the same wavefronts.  nseg = 0: one stretch, slots 0 .. n - 1, one class.
-#define RT_MAX_SEG 5
+// Where the rays of one launch are.  The queue is a row of regions of `stride` slots: one per signature class (a single
+// one for trees with BVH entries), filled from slot 0 of the region by the launch before, then one for the camera
+// rays generated since.  How many rays wait in each class region is read from device memory (`in_count`, counters
+// RT_COUNT_STRIDE apart, written by the launch before as its `out_count`), so that the host can queue launches
+// without waiting for those numbers; `fresh` it knows.  Every stretch starts a new workgroup (lockstep kernels).
+// in_count = null: one stretch, slots 0 .. n - 1 (caller-supplied batches).
 #define RT_COUNT_STRIDE 64u  // class counters sit 256 bytes apart: their atomics go to different cache lines
+#define RT_RING 4            // counter sets in rotation: the host queues launches RT_LAG iterations ahead of the counts it has read
+#define RT_LAG 2
+#define RT_RING_WORDS (4u * RT_COUNT_STRIDE)
 struct Segs {
-    uint32_t base[RT_MAX_SEG], count[RT_MAX_SEG], block0[RT_MAX_SEG + 1];  // block0[k]: first workgroup of stretch k
-    uint32_t nseg, nclass, out_stride;
+    const uint32_t* __restrict__ in_count;
+    uint32_t n;
+    uint32_t nclass, stride;
+    uint32_t fresh;
 };
 // Queue slot of this thread, or `end` (one past the last slot of its stretch) when it has none.
-__device__ __forceinline__ uint32_t seg_slot(const Segs& segs, uint32_t n, uint32_t& end) {
-    if (segs.nseg == 0u) {
-        end = n;
-        const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-        return idx < n ? idx : n;
+__device__ __forceinline__ uint32_t seg_slot(const Segs& segs, uint32_t& end) {
+    const uint32_t bs = blockDim.x;
+    if (segs.in_count == nullptr) {
+        end = segs.n;
+        const uint32_t idx = blockIdx.x * bs + threadIdx.x;
+        return idx < segs.n ? idx : segs.n;
     }
-    uint32_t seg_base = segs.base[0], seg_count = segs.count[0], seg_block0 = 0;
+    uint32_t base = 0, count = 0, block0 = 0, next = 0;
 #pragma unroll
-    for (uint32_t k = 1; k < RT_MAX_SEG; ++k)  // constant indices only: the argument block stays in scalar registers
-        if (k < segs.nseg && blockIdx.x >= segs.block0[k]) { seg_base = segs.base[k]; seg_count = segs.count[k]; seg_block0 = segs.block0[k]; }
-    const uint32_t local = (blockIdx.x - seg_block0) * blockDim.x + threadIdx.x;
-    end = seg_base + seg_count;
-    return local < seg_count ? seg_base + local : end;
+    for (uint32_t k = 0; k < 5u; ++k) {  // classes 0..3, then the fresh rays
+        if (k < 4u && k >= segs.nclass) continue;
+        const uint32_t c = k < 4u ? segs.in_count[RT_COUNT_STRIDE * k] : segs.fresh;
+        const uint32_t r = k < 4u ? k : segs.nclass;
+        if (blockIdx.x >= next) { base = r * segs.stride; count = c; block0 = next; }
+        next += (c + bs - 1u) / bs;
+    }
+    if (blockIdx.x >= next) count = 0;  // the host sized the grid for more rays than there are
+    const uint32_t local = (blockIdx.x - block0) * bs + threadIdx.x;
+    end = base + count;
+    return local < count ? base + local : end;
+}
+// The same rays as one numbered sequence 0 .. seg_total - 1 (the kernel that hands rays out; one class).
+__device__ __forceinline__ uint32_t seg_total(const Segs& segs) {
+    return segs.in_count == nullptr ? segs.n : segs.in_count[0] + segs.fresh;
+}
+__device__ __forceinline__ uint32_t seg_nth(const Segs& segs, uint32_t v) {
+    if (segs.in_count == nullptr) return v;
+    const uint32_t c0 = segs.in_count[0];
+    return v < c0 ? v : segs.stride + (v - c0);
 }
 
 // What a traverse launch works on: the queue of rays, where the closest hits go, and -- for caller-supplied batches
@@ -115,11 +137,10 @@ struct TravArgs {
     Queue q;
     HitBuf hb;
     uint64_t seed;
-    uint32_t n;
     const double* tmin;     // nullable
     const double* tmax;     // nullable
     uint32_t chunk;         // rays a wavefront of the persistent kernel takes per hand-out
-    Segs segs;              // lockstep kernel: where the rays are
+    Segs segs;              // where the rays are
 };
 __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, RngPos& rng, double& tmin, double& tmax) {
     rng.k0 = (uint32_t)a.seed; rng.k1 = (uint32_t)(a.seed >> 32);
@@ -142,12 +163,12 @@ __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long lo
 template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_lockstep(DScene S, TravArgs a, unsigned long long* tallies) {
     uint32_t n;
-    const uint32_t idx = seg_slot(a.segs, a.n, n);
+    const uint32_t idx = seg_slot(a.segs, n);
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     // with sorted queues the wavefront walks the copy of the tree without everything its rays' signatures rule out
     uint32_t first = 0u;
-    if (a.segs.nseg != 0u) first = tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
+    if (a.segs.in_count != nullptr) first = tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
     if (idx < n) {
         RngPos rng;
         double tmin, tmax;
@@ -181,6 +202,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
     uint32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
     uint32_t idx = 0xFFFFFFFFu;
+    const uint32_t total = seg_total(a.segs);
     Lane ln;
     ln.cur = ray_world(mk(0, 0, 0), mk(1, 1, 1));
     ln.cur_chain = 0; ln.i = 0; ln.k = 0; ln.kend = 0; ln.kind = 0; ln.s = 0; ln.e = 0;
@@ -210,15 +232,15 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
                     uint32_t base = 0;
                     if ((int)lane == leader) base = atomicAdd(work, a.chunk);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                    pool_next = base < a.n ? base : a.n;
-                    pool_end = (base + a.chunk) < a.n ? (base + a.chunk) : a.n;
-                    if (base >= a.n) { pool_end = pool_next; exhausted = true; }
+                    pool_next = base < total ? base : total;
+                    pool_end = (base + a.chunk) < total ? (base + a.chunk) : total;
+                    if (base >= total) { pool_end = pool_next; exhausted = true; }
                 }
                 if (!exhausted) {
                     if (need) {
                         const uint32_t mine = pool_next + (uint32_t)__popcll(mask & lt_mask);
                         if (mine < pool_end) {
-                            idx = mine;
+                            idx = seg_nth(a.segs, mine);
                             src.idx = idx;
                             double tmin, tmax;
                             trav_ray_setup(a, idx, rng, tmin, tmax);
@@ -391,14 +413,14 @@ __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8
 // radiance once into lum[] at its batch index.
 template <bool PLAIN>
 __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
-                                                       uint32_t n_all, Segs segs, Queue q, HitBuf hb,
+                                                       Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
                                                        uint32_t iter, uint32_t max_depth) {
     __shared__ uint32_t wave_total[SHADE_BLOCK / 64][4];
     __shared__ uint32_t block_base[4];
     uint32_t n;
-    const uint32_t idx = seg_slot(segs, n_all, n);
+    const uint32_t idx = seg_slot(segs, n);
     bool alive = false;
     V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
     uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
@@ -465,7 +487,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
     }
     __syncthreads();
     if (alive) {
-        uint32_t dst = cls * segs.out_stride + block_base[cls] + wave_total[wave][cls] + prefix;
+        uint32_t dst = cls * segs.stride + block_base[cls] + wave_total[wave][cls] + prefix;
         out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
         out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
@@ -486,7 +508,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     __shared__ uint32_t wave_total[BOUNCE_BLOCK / 64][4];
     __shared__ uint32_t block_base[4];
     uint32_t n;
-    const uint32_t idx = seg_slot(segs, 0u, n);
+    const uint32_t idx = seg_slot(segs, n);
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     bool alive = false;
@@ -562,7 +584,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     }
     __syncthreads();
     if (alive) {
-        uint32_t dst = cls * segs.out_stride + block_base[cls] + wave_total[wave][cls] + prefix;
+        uint32_t dst = cls * segs.stride + block_base[cls] + wave_total[wave][cls] + prefix;
         out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
         out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
@@ -678,6 +700,9 @@ struct rt_scene {
     const SigInfo* d_sig = nullptr;       // on the device
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ring_ev[RT_RING][4] = {};  // per queued iteration: start, after traverse, end, counts copied
+    uint32_t* d_ring = nullptr;           // RT_RING sets of class counters (RT_RING_WORDS words each)
+    uint32_t* h_ring = nullptr;           // pinned copy
     // render workspace, grown on demand
     size_t ws_paths = 0, ws_lum = 0, ws_hits = 0;
     std::vector<void*> ws_allocs;
@@ -713,6 +738,8 @@ void rt_scene_destroy(rt_scene* s) {
         free_list(s->ws_allocs);
         if (s->h_count) (void)hipHostFree(s->h_count);
         for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+        for (auto& r : s->ring_ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
+        if (s->h_ring) (void)hipHostFree(s->h_ring);
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
     delete s;
@@ -1006,6 +1033,10 @@ int rt_scene_commit(rt_scene* s, int device) {
 #undef UP
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& r : s->ring_ev) for (auto& e : r) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipHostMalloc((void**)&s->h_ring, RT_RING * RT_RING_WORDS * 4, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&s->d_ring, RT_RING * RT_RING_WORDS * 4));
+    s->allocs.push_back(s->d_ring);
     HIP_TRY(hipHostMalloc((void**)&s->h_count, 1024, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&s->d_count, 1024));
     s->allocs.push_back(s->d_count);
@@ -1070,11 +1101,13 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 }  // extern "C++"
 
 // One traverse+intersect launch over the rays of `a` on the scene's stream.
-static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocull = false, uint32_t blocks = 0) {
+// `n_upper`: no fewer rays than the launch will find (it sizes the grid; the kernels read the true numbers themselves).
+static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocull, uint32_t n_upper) {
     const size_t lds = levels_lds(s, TRAV_BLOCK);
     DScene d = s->d;
     if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
-    const uint32_t waves = blocks ? blocks : (a.n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    // every stretch of the queue starts a workgroup of its own
+    const uint32_t waves = (n_upper + TRAV_BLOCK - 1) / TRAV_BLOCK + (a.segs.in_count ? a.segs.nclass + 1u : 0u);
     if (!s->has_bvh) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
         if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
@@ -1088,7 +1121,7 @@ static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocu
         // RT_CHUNK rays per hand-out when there is plenty of work; fewer (down to one wavefront's worth) when the
         // launch is small, so that the rays spread over the whole device instead of queueing up behind a few waves
         TravArgs sized = a;
-        sized.chunk = std::max(64u, std::min(RT_CHUNK, (a.n / std::max(1u, s->persist_waves) + 63u) / 64u * 64u));
+        sized.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->persist_waves) + 63u) / 64u * 64u));
 #define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, sized, s->d_count + 4, s->d_tallies)
         if (count) PERSIST(true, RT_MEDIA_ANY);
         else if (s->media_mode == RT_MEDIA_NONE) PERSIST(false, RT_MEDIA_NONE);
@@ -1148,9 +1181,10 @@ int rt_intersect_batch(const rt_scene* s_, uint64_t seed, const double* o3, cons
         a.q.pix = d_pix; a.q.smp = d_smp; a.q.ctr = d_ctr;
         a.hb.t = d_ht; a.hb.ref = d_href; a.hb.chain = d_hchain;
         a.seed = seed;
-        a.n = (uint32_t)n;
+        a.segs.n = (uint32_t)n;
+        a.segs.nclass = 1u;
         a.tmin = d_tmin; a.tmax = d_tmax;
-        if ((rc = launch_traverse(s, a, false))) break;
+        if ((rc = launch_traverse(s, a, false, false, (uint32_t)n))) break;
         hipLaunchKernelGGL(k_finalize_batch, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s->stream, s->d, a.q, a.hb,
                            (uint32_t)n, d_hit, d_prim, d_t, d_p, d_n, d_uv, d_front, d_cout);
         hipError_t e = hipGetLastError();
@@ -1302,66 +1336,100 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         const uint64_t qcap = std::max<uint64_t>(std::min<uint64_t>(want, (uint64_t)npix * o->spp_count), bsize);
         const uint32_t nbatches = (o->spp_count + spb - 1) / spb;
         const uint32_t nslots = std::min<uint32_t>(o->max_depth + 1u, nbatches);
-        // Trees without BVH entries: rays that go on are sorted by signature class, one region of qcap slots per
-        // class, and new camera rays go to a region of their own behind those.  One bounce is one kernel (walk, shade
-        // and compaction together) or, on request and in counting passes (those kernels carry the counters), a
-        // traverse and a shade launch.
-        const bool sorted = !s->has_bvh;
-        const bool bounce = sorted && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
-        const uint32_t nclass = sorted ? 1u << s->sig.n : 1u;
-        const uint64_t rows = sorted ? (uint64_t)nclass * qcap + bsize : qcap;
+        // The queue is a row of regions of qcap slots: the rays that go on land in the region of their signature class
+        // (trees without BVH entries; one class otherwise), new camera rays in a region of their own behind those.
+        // Trees without BVH entries: one bounce is one kernel (walk, shade and compaction together) or, on request
+        // and in counting passes (those kernels carry the counters), a traverse and a shade launch.
+        const bool lockstep = !s->has_bvh;
+        const bool bounce = lockstep && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
+        const uint32_t nclass = lockstep ? 1u << s->sig.n : 1u;
+        const uint64_t rows = (uint64_t)nclass * qcap + bsize;
         if (rows > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
         if ((rc = ensure_workspace(s, (size_t)rows, (size_t)(bsize * nslots), bounce ? 0 : (size_t)rows))) return rc;
+        const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
+        auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
+        // How many rays each launch leaves behind is counted on the device, and the next launch reads it there.  The
+        // host reads those counts RT_LAG iterations late: until then it works with upper bounds (a ray count only
+        // falls from one iteration to the next, new camera rays aside), which size the grids and decide when the next
+        // batch fits; workgroups that find no rays leave at once.  So the device never waits for the host.
+        struct Launched { uint32_t fresh; uint32_t upper_in; };
+        std::vector<Launched> hist;            // per iteration queued
         std::vector<uint32_t> born_at(nbatches, 0);
         Queue qin = s->qa, qout = s->qb;
-        uint32_t n = 0, iter = 0, injected = 0, accumulated = 0;
-        uint32_t in_class[4] = {0, 0, 0, 0};  // rays waiting in each class region of qin (bounce kernel)
-        auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
-        for (;;) {
-            uint32_t fresh = 0;  // camera rays generated in this iteration
-            if (injected < nbatches && (uint64_t)n + bsize <= qcap) {
+        uint32_t injected = 0, accumulated = 0, consumed = 0, last_busy = 0;
+        uint32_t known_out = 0;                // exact number of rays iteration `consumed - 1` left behind
+        HIP_TRY(hipMemsetAsync(s->d_ring, 0, RT_RING_WORDS * 4, sm));  // nothing waits before iteration 0
+        auto consume = [&]() -> int {          // read what iteration `consumed` left behind
+            const uint32_t j = consumed, r = j % RT_RING, rn = (j + 1u) % RT_RING;
+            HIP_TRY(hipEventSynchronize(s->ring_ev[r][3]));
+            const uint32_t n_in = known_out + hist[j].fresh;
+            st.rays += n_in;
+            if (n_in) last_busy = j + 1u;
+            known_out = 0;
+            for (uint32_t c = 0; c < nclass; ++c) known_out += s->h_ring[rn * RT_RING_WORDS + RT_COUNT_STRIDE * c];
+            float ms = 0;
+            if (bounce) {
+                HIP_TRY(hipEventElapsedTime(&ms, s->ring_ev[r][0], s->ring_ev[r][2]));
+                st.ms_bounce += ms;
+                st.bounce_launches++;
+            } else {
+                HIP_TRY(hipEventElapsedTime(&ms, s->ring_ev[r][0], s->ring_ev[r][1]));
+                st.ms_traverse += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, s->ring_ev[r][1], s->ring_ev[r][2]));
+                st.ms_shade += ms;
+                st.traverse_launches++;
+            }
+            consumed++;
+            return RT_OK;
+        };
+        for (uint32_t iter = 0;; ++iter) {
+            if (iter >= RT_LAG && consumed + RT_LAG <= iter && (rc = consume())) return rc;
+            // no more rays than this can be waiting: the last exact count plus the camera rays generated since
+            uint64_t upper = known_out;
+            for (uint32_t j = consumed; j < iter; ++j) upper += hist[j].fresh;
+            // batches all of whose paths are finished go to the film, oldest first (a path lives max_depth iterations
+            // at most; and once a launch is known to have left nothing behind, everything generated before it is done)
+            while (accumulated < injected &&
+                   (iter - born_at[accumulated] >= o->max_depth || (known_out == 0 && consumed > born_at[accumulated]))) {
+                const uint32_t slot0 = (uint32_t)((accumulated % nslots) * bsize);
+                hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + slot0,
+                                   s->lum_g + slot0, s->lum_b + slot0, npix, batch_samples(accumulated), film);
+                accumulated++;
+            }
+            uint32_t fresh = 0;  // camera rays generated for this iteration
+            if (injected < nbatches && upper + bsize <= qcap) {
                 // a slot is reused only after its previous batch has been added to the film
                 if (injected >= nslots && accumulated + nslots <= injected) return fail(RT_ERR_STATE, "luminance slot still in use");
                 const uint32_t ns = batch_samples(injected), nb = ns * npix;
                 const uint32_t slot0 = (uint32_t)((injected % nslots) * bsize);
                 hipLaunchKernelGGL(k_raygen, dim3((nb + 255u) / 256u), dim3(256), 0, sm, s->d_sig, *cam, o->seed, npix,
-                                   o->spp_begin + injected * spb, nb, sorted ? nclass * (uint32_t)qcap : n, slot0, iter, qin);
+                                   o->spp_begin + injected * spb, nb, nclass * (uint32_t)qcap, slot0, iter, qin);
                 born_at[injected] = iter;
                 injected++;
-                n += nb;
                 fresh = nb;
                 st.paths += nb;
             }
-            if (n == 0) break;  // nothing in flight and nothing left to inject
-            st.rays += n;
-            HIP_TRY(hipMemsetAsync(s->d_count, 0, 1024, sm));
-            HIP_TRY(hipEventRecord(s->ev[1], sm));
-            // where this launch's rays are, for workgroups of `bs` threads
-            auto make_segs = [&](uint32_t bs, uint32_t& blocks) {
-                Segs segs;
-                std::memset(&segs, 0, sizeof segs);
-                segs.nclass = nclass;
-                segs.out_stride = (uint32_t)qcap;
-                blocks = (n + bs - 1) / bs;
-                if (!sorted) return segs;
-                blocks = 0;
-                auto add_seg = [&](uint32_t base, uint32_t cnt) {
-                    if (!cnt) return;
-                    segs.base[segs.nseg] = base; segs.count[segs.nseg] = cnt; segs.block0[segs.nseg] = blocks;
-                    blocks += (cnt + bs - 1) / bs;
-                    segs.block0[++segs.nseg] = blocks;
-                };
-                for (uint32_t c = 0; c < nclass; ++c) add_seg(c * (uint32_t)qcap, in_class[c]);
-                add_seg(nclass * (uint32_t)qcap, fresh);
-                return segs;
-            };
-            const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
+            const uint32_t upper_in = (uint32_t)(upper + fresh);
+            if (upper_in == 0) {
+                if (injected == nbatches) break;  // nothing in flight and nothing left to generate
+                return fail(RT_ERR_STATE, "queue empty with batches left");
+            }
+            hist.push_back({fresh, upper_in});
+            const uint32_t r = iter % RT_RING, rn = (iter + 1u) % RT_RING;
+            uint32_t* const out_count = s->d_ring + rn * RT_RING_WORDS;
+            Segs segs;
+            std::memset(&segs, 0, sizeof segs);
+            segs.in_count = s->d_ring + r * RT_RING_WORDS;
+            segs.nclass = nclass;
+            segs.stride = (uint32_t)qcap;
+            segs.fresh = fresh;
+            HIP_TRY(hipMemsetAsync(out_count, 0, RT_RING_WORDS * 4, sm));
+            HIP_TRY(hipEventRecord(s->ring_ev[r][0], sm));
             if (bounce) {
                 DScene d = s->d;
                 if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
-                uint32_t blocks = 0;
-                const Segs segs = make_segs(BOUNCE_BLOCK, blocks);
-#define BOUNCE_ARGS d, s->d_sig, o->seed, segs, qin, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
+                const uint32_t blocks = (upper_in + BOUNCE_BLOCK - 1) / BOUNCE_BLOCK + nclass + 1u;
+#define BOUNCE_ARGS d, s->d_sig, o->seed, segs, qin, qout, out_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
                     o->background[1], o->background[2], iter, o->max_depth
 #define BOUNCE(M, P) hipLaunchKernelGGL((k_bounce_lockstep<M, P>), dim3(blocks), dim3(BOUNCE_BLOCK), \
                                         levels_lds(s, BOUNCE_BLOCK), sm, BOUNCE_ARGS)
@@ -1370,50 +1438,34 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                 else { if (s->plain) BOUNCE(RT_MEDIA_ANY, true); else BOUNCE(RT_MEDIA_ANY, false); }
 #undef BOUNCE
 #undef BOUNCE_ARGS
-                HIP_TRY(hipEventRecord(s->ev[2], sm));
             } else {
                 TravArgs ta;
                 std::memset(&ta, 0, sizeof ta);
-                ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.n = n;
-                uint32_t tblocks = 0, sblocks = 0;
-                ta.segs = make_segs(TRAV_BLOCK, tblocks);
-                if ((rc = launch_traverse(s, ta, count, nocull, tblocks))) return rc;
-                HIP_TRY(hipEventRecord(s->ev[2], sm));
-                const Segs ssegs = make_segs(SHADE_BLOCK, sblocks);
-#define SHADE_ARGS s->d, s->d_sig, o->seed, n, ssegs, qin, s->hb, qout, s->d_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
+                ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.segs = segs;
+                if ((rc = launch_traverse(s, ta, count, nocull, upper_in))) return rc;
+                HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
+                const uint32_t sblocks = (upper_in + SHADE_BLOCK - 1) / SHADE_BLOCK + nclass + 1u;
+#define SHADE_ARGS s->d, s->d_sig, o->seed, segs, qin, s->hb, qout, out_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
                    o->background[1], o->background[2], iter, o->max_depth
                 if (s->plain) hipLaunchKernelGGL(k_shade<true>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
                 else hipLaunchKernelGGL(k_shade<false>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
 #undef SHADE_ARGS
             }
-            HIP_TRY(hipEventRecord(s->ev[3], sm));
-            HIP_TRY(hipMemcpyAsync(s->h_count, s->d_count, 1024, hipMemcpyDeviceToHost, sm));
-            HIP_TRY(hipStreamSynchronize(sm));
+            HIP_TRY(hipEventRecord(s->ring_ev[r][2], sm));
+            HIP_TRY(hipMemcpyAsync(s->h_ring + rn * RT_RING_WORDS, out_count, RT_RING_WORDS * 4, hipMemcpyDeviceToHost, sm));
+            HIP_TRY(hipEventRecord(s->ring_ev[r][3], sm));
             HIP_TRY(hipGetLastError());
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
-            if (bounce) {
-                st.ms_bounce += ms;
-                st.bounce_launches++;
-            } else {
-                st.ms_traverse += ms;
-                HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
-                st.ms_shade += ms;
-                st.traverse_launches++;
-            }
-            n = 0;
-            for (uint32_t c = 0; c < nclass; ++c) { in_class[c] = s->h_count[RT_COUNT_STRIDE * c]; n += in_class[c]; }
             std::swap(qin, qout);
-            iter++;
-            // batches whose paths are all finished go to the film, oldest first
-            while (accumulated < injected && (n == 0 || iter - born_at[accumulated] >= o->max_depth)) {
-                const uint32_t slot0 = (uint32_t)((accumulated % nslots) * bsize);
-                hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + slot0,
-                                   s->lum_g + slot0, s->lum_b + slot0, npix, batch_samples(accumulated), film);
-                accumulated++;
-            }
         }
-        st.bounces = std::min(iter, o->max_depth);
+        while (consumed < hist.size()) if ((rc = consume())) return rc;
+        if (known_out != 0) return fail(RT_ERR_STATE, "rays left in the queue");
+        while (accumulated < injected) {  // (a render of depth 0 generates nothing; everything else was added above)
+            const uint32_t slot0 = (uint32_t)((accumulated % nslots) * bsize);
+            hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + slot0,
+                               s->lum_g + slot0, s->lum_b + slot0, npix, batch_samples(accumulated), film);
+            accumulated++;
+        }
+        st.bounces = std::min(last_busy, o->max_depth);
     }
     HIP_TRY(hipEventRecord(s->ev[3], sm));
     HIP_TRY(hipStreamSynchronize(sm));
