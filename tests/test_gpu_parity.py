@@ -271,6 +271,26 @@ def test_full_resolution_bvh_scene_properties():
         scene.close()
 
 
+@pytest.mark.parametrize("cfg", ["C2", "C5"])
+def test_many_small_batches_through_the_counter_ring(gpu_scenes, cfg):
+    """The host queues launches ahead of the ray counts it has read and rotates through a few sets of device
+    counters.  A queue that holds one sample of every pixel at a time forces one batch per iteration for many
+    iterations (sets reused many times, batches finishing while later ones are in flight, luminance sections
+    recycled); a depth of 1 and of 2 ends paths before the first counts are read.  Same film bit for bit as with
+    everything in one batch, and the same ray count."""
+    hs, _, scene = gpu_scenes(cfg)
+    hc, _ = cameras(hs)
+    npix = hc.width * hc.height
+    for depth in (hs.max_depth, 2, 1):
+        want, st_w = scene.render(hc, 37, depth, hs.background, spp_begin=3)
+        got, st_g = scene.render(hc, 37, depth, hs.background, spp_begin=3, batch_paths=npix)
+        assert np.array_equal(got, want), depth
+        assert st_g["rays"] == st_w["rays"] and st_g["paths"] == st_w["paths"] == 37 * npix
+        launches = st_g["bounce_launches"] + st_g["traverse_launches"]
+        assert launches >= 37 and launches > st_w["bounce_launches"] + st_w["traverse_launches"]
+        assert st_g["bounces"] == st_w["bounces"] <= depth
+
+
 def test_render_multi_splits_samples_and_adds_shards_in_rank_order():
     """rt_render_multi on a one-GPU box: the same scene committed three times to device 0 stands in for three GPUs.
     The result must be, bit for bit, the rank-ordered sum of the three shard renders (7 samples -> 3 + 2 + 2)."""
