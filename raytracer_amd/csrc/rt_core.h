@@ -663,6 +663,18 @@ RT_HD uint32_t tree_without(const DScene& S, uint32_t skip_mask) {
     return (skip_mask & (S.n_variants - 1u)) * S.n_nodes;
 }
 
+// The same against the cull box of a BVH entry, six f32 (rounded outwards when the records were built) in the fifth
+// and sixth 16-byte unit of the record.
+template <bool COUNT>
+RT_HD bool cull_pass_f32(const DScene& S, uint32_t i, Ray& cur, double s, double e, Tally& tally) {
+    if (COUNT) tally.cull_tests++;
+    ray_need_inv(cur);
+    const float* f = reinterpret_cast<const float*>(S.nodes + 8u * i + 4u);
+    double2 cx, cy, cz;
+    cx.x = f[0]; cx.y = f[1]; cy.x = f[2]; cy.y = f[3]; cz.x = f[4]; cz.y = f[5];
+    return slab3(cx, cy, cz, cur, s, e);
+}
+
 // BVHNode::hit's box test (bvh.rs:31-37) for the entry `n` at index i: returns the index to go on with.
 template <bool COUNT>
 RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels& L, const Best& best, Ray& cur,
@@ -671,7 +683,7 @@ RT_HD uint32_t bvh_step(const DScene& S, const Node& n, uint32_t i, const Levels
     double2 iv = lv_get(L, n.level);
     double s = iv.x, e = fmin(iv.y, best.t);
     if (COUNT) tally.node_tests++;
-    if (!cull_pass<COUNT>(S, i, 4u, cur, s, e, tally)) return n.skip;
+    if (!cull_pass_f32<COUNT>(S, i, cur, s, e, tally)) return n.skip;
     if (slab(reinterpret_cast<const double2*>(S.nodes + 8u * i + 1u), cur, s, e)) {
         lv_set(L, n.level + 1u, s, e);
         return i + 1u;
@@ -973,17 +985,19 @@ RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const 
 template <bool COUNT, int MEDIA = RT_MEDIA_ANY, class Src>
 RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Levels& L, RngPos& rng, Tally& tally) {
     if (ln.i >= S.n_nodes) { ln.state = RT_ST_DONE; return; }
-    // The whole 128-byte record at once, whatever its kind: the boxes and the leaf's run sit in the same cache line
-    // as the header, and fetching them together costs one round trip instead of one per dependent step.
+    // Everything the record holds at once, whatever its kind (96 bytes, six loads): the boxes sit in the same cache
+    // line as the header, which also names a leaf's run of primitives, and fetching them together costs one round
+    // trip instead of one per dependent step.
     const uint4* rp = S.nodes + 8u * ln.i;
     const double2* bp = reinterpret_cast<const double2*>(rp);
     const uint4 raw = rp[0];
-    const double2 b0 = bp[1], b1 = bp[2], b2 = bp[3], c0 = bp[4], c1 = bp[5], c2 = bp[6];
-    const uint4 leaf = rp[7];
+    const double2 b0 = bp[1], b1 = bp[2], b2 = bp[3];
+    const float4 cf0 = reinterpret_cast<const float4*>(rp)[4];
+    const float2 cf1 = reinterpret_cast<const float2*>(rp)[10];
     const double2 iv0 = lv_get(L, raw.x >> 8 & 0xFFu);
 #if defined(__HIP_DEVICE_COMPILE__)
     // keeps the compiler from sinking the loads into the branches below, where each would wait on its own
-    asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(c0.x), "v"(c1.x), "v"(c2.x), "v"(leaf.x), "v"(leaf.y), "v"(leaf.z));
+    asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(cf0.x), "v"(cf1.x));
 #endif
     Node n;
     n.kind = raw.x & 0xFFu; n.level = raw.x >> 8 & 0xFFu; n.chain = raw.x >> 16;
@@ -1000,13 +1014,15 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         if (COUNT) { tally.node_tests++; tally.cull_tests++; }
         {
             double cs = s, ce = e;  // the cull box narrows nothing
+            double2 c0, c1, c2;
+            c0.x = cf0.x; c0.y = cf0.y; c1.x = cf0.z; c1.y = cf0.w; c2.x = cf1.x; c2.y = cf1.y;
             if (!slab3(c0, c1, c2, ln.cur, cs, ce)) { ln.i = n.skip; return; }
         }
         if (!slab3(b0, b1, b2, ln.cur, bs, be)) { ln.i = n.skip; return; }
-        if (leaf.x != 0u) {
+        if (n.count != 0u) {
             // a leaf whose children are one run of primitives (the usual case): go straight to the run with the
             // narrowed interval in registers, without a round trip through the level slots
-            ln.kind = leaf.x; ln.k = leaf.y; ln.kend = leaf.y + leaf.z;
+            ln.kind = n.count >> 24; ln.k = n.first; ln.kend = n.first + (n.count & 0xFFFFFFu);
             ln.s = bs; ln.e = be;
             ln.i = ln.i + 1u;
             ln.state = RT_ST_RUN;

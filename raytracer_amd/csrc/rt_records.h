@@ -5,10 +5,12 @@
 //                   a CULL entry's `count` is 1 when it is a signature entry (see signature_nodes) in `pruned`: the
 //                   lockstep walk passes it over; a medium with nothing but such an entry becomes one itself
 //   bytes  16..63   BVH entry: the reference's box (3 x (start, end)); CULL entry: its box
-//   bytes  64..111  BVH entry: conservative cull box (infinite when the caller supplied none)
-//   bytes 112..127  BVH entry whose subtree is exactly one run of primitives in the same chain (a leaf, the usual
-//                   case): kind, first, count of that run, so that the walk goes from the box test straight to the
-//                   primitives; kind 0 otherwise
+//   bytes  64..87   BVH entry: conservative cull box as six f32 (x, y, z: start, end), rounded outwards (infinite when
+//                   the caller supplied none).  A BVH entry's header carries, in place of the box index the device has
+//                   no use for, the run of primitives that is its whole subtree when it is a leaf in the same chain
+//                   (the usual case), so that the walk goes from the box test straight to the primitives:
+//                   `first` = first primitive, `count` = kind << 24 | count; count 0 otherwise.  The walk reads the first
+//                   96 bytes of such a record (six 16-byte loads).
 //
 // `cull` = false gives the records that switch every cull box off: infinite boxes, and a CULL entry's skip
 // pointing at the next entry, because a ray whose interval is already empty fails even an infinite box.
@@ -50,11 +52,23 @@ inline std::vector<uint32_t> build_records(const rt_node* nodes, size_t n_nodes,
             n.count = flat ? 1u : 0u;
         } else if (n.kind == RT_NODE_BVH) {
             std::memcpy(r + 4, boxes + 6 * (size_t)n.first, 48);
-            std::memcpy(r + 16, (cull && cull_boxes) ? cull_boxes + 6 * (size_t)n.first : everything, 48);
+            const double* cb = (cull && cull_boxes) ? cull_boxes + 6 * (size_t)n.first : everything;
+            float cf[6];
+            for (int k = 0; k < 6; ++k) {
+                float f = (float)cb[k];
+                if (!(k & 1) && (double)f > cb[k]) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+                if ((k & 1) && (double)f < cb[k]) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+                cf[k] = f;
+            }
+            std::memcpy(r + 16, cf, 24);
+            n.first = 0u;
+            n.count = 0u;
             if (n.skip == i + 2) {
                 const rt_node& c = nodes[i + 1];
-                if (c.kind >= RT_NODE_SPHERES && c.kind <= RT_NODE_QUADRICS && c.count > 0 && c.chain == n.chain) {
-                    r[28] = c.kind; r[29] = c.first; r[30] = c.count;
+                if (c.kind >= RT_NODE_SPHERES && c.kind <= RT_NODE_QUADRICS && c.count > 0 && c.count < (1u << 24) &&
+                    c.chain == n.chain) {
+                    n.first = c.first;
+                    n.count = (uint32_t)c.kind << 24 | c.count;
                 }
             }
         } else if (n.kind == RT_NODE_CULL) {
