@@ -993,11 +993,13 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
     const uint4 raw = rp[0];
     const double2 b0 = bp[1], b1 = bp[2], b2 = bp[3];
     const float4 cf0 = reinterpret_cast<const float4*>(rp)[4];
-    const float2 cf1 = reinterpret_cast<const float2*>(rp)[10];
+    const uint4 tail = rp[5];  // two more f32 of that box, then (CULL entries) the next sibling's skip and flag
+    float2 cf1;
+    cf1.x = __builtin_bit_cast(float, tail.x); cf1.y = __builtin_bit_cast(float, tail.y);
     const double2 iv0 = lv_get(L, raw.x >> 8 & 0xFFu);
 #if defined(__HIP_DEVICE_COMPILE__)
     // keeps the compiler from sinking the loads into the branches below, where each would wait on its own
-    asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(cf0.x), "v"(cf1.x));
+    asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(cf0.x), "v"(tail.x));
 #endif
     Node n;
     n.kind = raw.x & 0xFFu; n.level = raw.x >> 8 & 0xFFu; n.chain = raw.x >> 16;
@@ -1035,7 +1037,17 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
     if (n.kind == RT_NODE_CULL) {
         if (COUNT) tally.cull_tests++;
         double cs = s, ce = e;
-        ln.i = slab3(b0, b1, b2, ln.cur, cs, ce) ? ln.i + 1u : n.skip;
+        if (slab3(b0, b1, b2, ln.cur, cs, ce)) { ln.i = ln.i + 1u; return; }
+        ln.i = n.skip;
+        if (tail.w != 0u) {
+            // a row of boxes: the record also holds the box of the CULL entry at n.skip (widened to f32), so a miss
+            // here decides about that one in the same step -- straight into its subtree, or past it
+            if (COUNT) tally.cull_tests++;
+            double2 c0, c1, c2;
+            c0.x = cf0.x; c0.y = cf0.y; c1.x = cf0.z; c1.y = cf0.w; c2.x = cf1.x; c2.y = cf1.y;
+            cs = s; ce = e;
+            ln.i = slab3(c0, c1, c2, ln.cur, cs, ce) ? n.skip + 1u : tail.z;
+        }
         return;
     }
     if (MEDIA != RT_MEDIA_NONE && n.kind == RT_NODE_MEDIUM) {

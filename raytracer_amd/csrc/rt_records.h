@@ -5,6 +5,8 @@
 //                   a CULL entry's `count` is 1 when it is a signature entry (see signature_nodes) in `pruned`: the
 //                   lockstep walk passes it over; a medium with nothing but such an entry becomes one itself
 //   bytes  16..63   BVH entry: the reference's box (3 x (start, end)); CULL entry: its box
+//   bytes  64..95   CULL entry followed, after its subtree, by another CULL entry of the same level and chain: that
+//                   entry's box as six f32 rounded outwards, its `skip`, and 1; zeros otherwise
 //   bytes  64..87   BVH entry: conservative cull box as six f32 (x, y, z: start, end), rounded outwards (infinite when
 //                   the caller supplied none).  A BVH entry's header carries, in place of the box index the device has
 //                   no use for, the run of primitives that is its whole subtree when it is a leaf in the same chain
@@ -25,6 +27,16 @@
 #include "rt_amd.h"
 
 namespace rt {
+
+// A box (x, y, z: start, end) as f32, every bound rounded away from the inside.
+inline void outward_f32(const double* box6, float* out6) {
+    for (int k = 0; k < 6; ++k) {
+        float f = (float)box6[k];
+        if (!(k & 1) && (double)f > box6[k]) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+        if ((k & 1) && (double)f < box6[k]) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+        out6[k] = f;
+    }
+}
 
 inline std::vector<uint32_t> build_records(const rt_node* nodes, size_t n_nodes, const double* boxes,
                                            const double* cull_boxes, bool cull, bool one_pass_media,
@@ -52,14 +64,8 @@ inline std::vector<uint32_t> build_records(const rt_node* nodes, size_t n_nodes,
             n.count = flat ? 1u : 0u;
         } else if (n.kind == RT_NODE_BVH) {
             std::memcpy(r + 4, boxes + 6 * (size_t)n.first, 48);
-            const double* cb = (cull && cull_boxes) ? cull_boxes + 6 * (size_t)n.first : everything;
             float cf[6];
-            for (int k = 0; k < 6; ++k) {
-                float f = (float)cb[k];
-                if (!(k & 1) && (double)f > cb[k]) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
-                if ((k & 1) && (double)f < cb[k]) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
-                cf[k] = f;
-            }
+            outward_f32((cull && cull_boxes) ? cull_boxes + 6 * (size_t)n.first : everything, cf);
             std::memcpy(r + 16, cf, 24);
             n.first = 0u;
             n.count = 0u;
@@ -73,6 +79,18 @@ inline std::vector<uint32_t> build_records(const rt_node* nodes, size_t n_nodes,
             }
         } else if (n.kind == RT_NODE_CULL) {
             std::memcpy(r + 4, cull ? boxes + 6 * (size_t)n.first : everything, 48);
+            // the CULL entry that follows this one's subtree at the same level (the next box of a row of boxes), so
+            // that a lane failing this box tests the next in the same step
+            if (cull && n.skip < n_nodes) {
+                const rt_node& nx = nodes[n.skip];
+                if (nx.kind == RT_NODE_CULL && nx.chain == n.chain && nx.level == n.level) {
+                    float cf[6];
+                    outward_f32(boxes + 6 * (size_t)nx.first, cf);
+                    std::memcpy(r + 16, cf, 24);
+                    r[22] = nx.skip + index_base;
+                    r[23] = 1u;
+                }
+            }
             n.count = 0u;
             for (size_t b = 0; cull && b < sig_nodes.size(); ++b)
                 if (sig_nodes[b] == i && ((pruned >> b) & 1u)) n.count = 1u;  // the lockstep walk passes it over
