@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
 #define RT_FETCH_THRESHOLD 16
 #define RT_MEDIUM_THRESHOLD 18
 #define RT_CHAIN_THRESHOLD 12
+#define RT_SUB_THRESHOLD 12
 template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
@@ -218,9 +219,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
         int n_run = __popcll(__ballot(ln.state == RT_ST_RUN));
         int n_med = MEDIA != RT_MEDIA_NONE ? __popcll(__ballot(ln.state == RT_ST_MEDIUM)) : 0;
         const int n_chain = __popcll(__ballot(ln.state == RT_ST_CHAIN));
+        const int n_sub = __popcll(__ballot(ln.state == RT_ST_SUB));
         // hand out rays only when enough lanes are free (or nobody has work): the hand-out code costs the whole
         // wavefront its instructions however few lanes it serves
-        if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run + n_med + n_chain == 0)) {
+        if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run + n_med + n_chain + n_sub == 0)) {
             if (need && idx != 0xFFFFFFFFu) {
                 a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
                 a.q.ctr[idx] = rng.ctr;
@@ -261,7 +263,9 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
         const bool do_run = n_run >= RT_STEP_THRESHOLD || n_run > n_node;
         const bool do_med = MEDIA != RT_MEDIA_NONE && (n_med >= RT_MEDIUM_THRESHOLD || (n_med > 0 && n_node + n_run == 0));
         const bool do_chain = n_chain >= RT_CHAIN_THRESHOLD || (n_chain > 0 && n_node + n_run == 0);
+        const bool do_sub = n_sub >= RT_SUB_THRESHOLD || (n_sub > 0 && n_node + n_run == 0);
         if (do_chain && ln.state == RT_ST_CHAIN) lane_chain_step(S, src, ln);
+        if (do_sub && ln.state == RT_ST_SUB) lane_sub_step<COUNT>(S, ln, tally);
         if (do_node && ln.state == RT_ST_NODE) lane_node_step<COUNT, MEDIA>(S, src, ln, L, rng, tally);
         if (do_run && ln.state == RT_ST_RUN) lane_prim_step<COUNT>(S, ln, tally);
         if (MEDIA != RT_MEDIA_NONE) {
@@ -999,6 +1003,10 @@ int rt_scene_commit(rt_scene* s, int device) {
             if (!flat) s->media_mode = RT_MEDIA_ANY;
             else if (s->media_mode == RT_MEDIA_NONE) s->media_mode = RT_MEDIA_FLAT;
         }
+        std::vector<float> leaf_boxes;
+        if (s->has_bvh) build_leaf_boxes(s->nodes.data(), s->nodes.size(), s->tris.data(), s->quads.data(), rec, leaf_boxes);
+        leaf_boxes.resize(leaf_boxes.size() + 48, 0.0f);
+        if ((rc = upload(s, leaf_boxes, &d.leaf_sub))) return rc;
         std::vector<uint32_t> rec_nc = build_records(s->nodes.data(), s->nodes.size(), s->boxes.data(), cb, false, true);
         const uint32_t *d_rec = nullptr, *d_rec_nc = nullptr;
         if ((rc = upload(s, rec, &d_rec))) return rc;

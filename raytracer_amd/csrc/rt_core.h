@@ -230,6 +230,8 @@ struct DScene {
     const uint32_t* sphere_mat; const uint32_t* sphere_id;
     const uint32_t* quad_mat;   const uint32_t* quad_id;
     const uint32_t* quad_axis;  // per quad: 1 + the axis its normal lies along when n and w are zero elsewhere, else 0
+    const float* leaf_sub;      // per BVH leaf that has them (records, bytes 88..91): cull boxes of its pairs of primitives,
+                                // 8 x 6 f32
     uint32_t n_variants;        // copies of the tree in `nodes` (1, 2 or 4), n_nodes entries each: copy m is the tree
                                 // without the subtrees of the signature entries in mask m (a pruned CULL entry has
                                 // count 1 and the lockstep walk passes its subtree over); indices in copy m count
@@ -958,11 +960,14 @@ RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax
 #define RT_ST_DONE 2u
 #define RT_ST_MEDIUM 3u  // standing on a MEDIUM entry, waiting for lane_medium_step
 #define RT_ST_CHAIN 4u   // standing on an entry of another instance chain, waiting for lane_chain_step
+#define RT_ST_SUB 5u     // about to start a leaf's run that has cull boxes per pair of primitives, waiting for lane_sub_step
 struct Lane {
     Ray cur;
     uint32_t cur_chain;
     uint32_t i;              // next entry of the flattened tree
-    uint32_t k, kend, kind;  // primitive run in progress (RT_ST_RUN)
+    uint32_t k, kend, kind;  // primitive run in progress (RT_ST_RUN); kind: bits 0..7 the kind; bit 8 set: bits 16..23
+                             // say which of the pairs k, k + 2, ... are worth testing (bit 16 = the pair at k);
+                             // RT_ST_SUB: bits 8.. the leaf's index into leaf_sub
     double s, e;             // interval the run in progress is tested against
     Best best;
     uint32_t state;
@@ -1028,6 +1033,7 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
             ln.s = bs; ln.e = be;
             ln.i = ln.i + 1u;
             ln.state = RT_ST_RUN;
+            if (tail.z != 0u) { ln.kind |= (tail.z - 1u) << 8; ln.state = RT_ST_SUB; }
             return;
         }
         lv_set(L, n.level + 1u, bs, be);
@@ -1104,25 +1110,32 @@ RT_HD void lane_medium_step(const DScene& S, const Src& src, Lane& ln, const Lev
 }
 // The next primitive(s) of the run in progress for a lane in RT_ST_RUN: two per step where the run has two left, so
 // that both records are in flight together and the step's fixed costs are shared.
+// Moves a lane whose run has a pair mask (bit 0 of `mask` = the pair at ln.k) on to the next pair worth testing.
+RT_HD void lane_skip_pairs(Lane& ln, uint32_t mask) {
+    mask &= 0xFFu;
+    while (ln.k < ln.kend && (mask & 1u) == 0u) { ln.k += 2u; mask >>= 1; }
+    ln.kind = (ln.kind & 0xFFFFu) | mask << 16;
+}
 template <bool COUNT>
 RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
     const bool two = ln.k + 1u < ln.kend;
     double t;
-    if (ln.kind == RT_NODE_TRIANGLES || ln.kind == RT_NODE_QUADS) {
-        const bool is_tri = ln.kind == RT_NODE_TRIANGLES;
+    const uint32_t kind = ln.kind & 0xFFu;
+    if (kind == RT_NODE_TRIANGLES || kind == RT_NODE_QUADS) {
+        const bool is_tri = kind == RT_NODE_TRIANGLES;
         const double2* rec = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads) + 8u * ln.k;
         const Planar g0 = load_planar(rec);
         const Planar g1 = load_planar(rec + (two ? 8u : 0u));
         if (COUNT) { tally.prim_tests += two ? 2u : 1u; tally.prim_bytes += two ? 272u : 136u; tally.prim_flops += two ? 120u : 60u; }
         if (planar_t(g0, is_tri, ln.cur, ln.s, ln.e, t)) {
-            ln.best.t = t; ln.best.ref = make_ref(ln.kind, ln.k); ln.best.chain = ln.cur_chain;
+            ln.best.t = t; ln.best.ref = make_ref(kind, ln.k); ln.best.chain = ln.cur_chain;
             ln.e = t;
         }
         if (two && planar_t(g1, is_tri, ln.cur, ln.s, ln.e, t)) {
-            ln.best.t = t; ln.best.ref = make_ref(ln.kind, ln.k + 1u); ln.best.chain = ln.cur_chain;
+            ln.best.t = t; ln.best.ref = make_ref(kind, ln.k + 1u); ln.best.chain = ln.cur_chain;
             ln.e = t;
         }
-    } else if (ln.kind == RT_NODE_SPHERES) {
+    } else if (kind == RT_NODE_SPHERES) {
         // up to four spheres per step: their records (32 bytes each) share one 128-byte line
         const double2* rec = reinterpret_cast<const double2*>(S.spheres) + 2u * ln.k;
         const uint32_t left = ln.kend - ln.k, done = left < 4u ? left : 4u;
@@ -1151,6 +1164,35 @@ RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
         return;
     }
     ln.k = ln.k + (two ? 2u : 1u);
+    if (ln.kind & 0x100u) lane_skip_pairs(ln, (ln.kind >> 16) >> 1);
+    if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
+}
+// A leaf's run with cull boxes per pair of primitives (no counterpart in the reference; results unchanged: a pair is
+// passed over only when the ray's interval cannot touch the box around its corners).  One step tests all eight
+// boxes and moves the lane to the first pair worth testing, or past the run.
+template <bool COUNT>
+RT_HD void lane_sub_step(const DScene& S, Lane& ln, Tally& tally) {
+    const float4* bp = reinterpret_cast<const float4*>(S.leaf_sub + 48u * (ln.kind >> 8));
+    float4 f[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) f[j] = bp[j];
+    if (COUNT) tally.cull_tests += 8u;
+    const double e = fmin(ln.e, ln.best.t);
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) {  // two boxes in three float4
+        const float4 p = f[3 * (b / 2)], q = f[3 * (b / 2) + 1], r = f[3 * (b / 2) + 2];
+        double2 x0, y0, z0, x1, y1, z1;
+        x0.x = p.x; x0.y = p.y; y0.x = p.z; y0.y = p.w; z0.x = q.x; z0.y = q.y;
+        x1.x = q.z; x1.y = q.w; y1.x = r.x; y1.y = r.y; z1.x = r.z; z1.y = r.w;
+        double cs = ln.s, ce = e;
+        if (slab3(x0, y0, z0, ln.cur, cs, ce)) mask |= 1u << b;
+        cs = ln.s; ce = e;
+        if (slab3(x1, y1, z1, ln.cur, cs, ce)) mask |= 2u << b;
+    }
+    ln.kind = (ln.kind & 0xFFu) | 0x100u;
+    ln.state = RT_ST_RUN;
+    lane_skip_pairs(ln, mask);
     if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
 }
 

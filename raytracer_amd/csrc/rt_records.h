@@ -7,6 +7,8 @@
 //   bytes  16..63   BVH entry: the reference's box (3 x (start, end)); CULL entry: its box
 //   bytes  64..95   CULL entry followed, after its subtree, by another CULL entry of the same level and chain: that
 //                   entry's box as six f32 rounded outwards, its `skip`, and 1; zeros otherwise
+//   bytes  88..91   BVH entry that is such a leaf and has cull boxes per pair of primitives (build_leaf_boxes): 1 + its
+//                   index among those leaves
 //   bytes  64..87   BVH entry: conservative cull box as six f32 (x, y, z: start, end), rounded outwards (infinite when
 //                   the caller supplied none).  A BVH entry's header carries, in place of the box index the device has
 //                   no use for, the run of primitives that is its whole subtree when it is a leaf in the same chain
@@ -18,6 +20,7 @@
 // pointing at the next entry, because a ray whose interval is already empty fails even an infinite box.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -27,6 +30,45 @@
 #include "rt_amd.h"
 
 namespace rt {
+
+// Cull boxes inside the leaves of a BVH (no counterpart in the reference; results unchanged).  The reference puts up
+// to 16 primitives in a leaf and tests all of them once the leaf's box is hit.  For every BVH leaf that is one run
+// of 3..16 triangles or quads in its own chain, eight boxes go to `out` (8 x 6 f32, rounded outwards; empty past the
+// end of the run): box j bounds the corners of primitives 2j and 2j + 1 of the run, widened by
+// 1e-5 (1 + |coordinate|) like the cull boxes the host layer supplies.  The leaf's record (in `rec`, as built by
+// build_records with cull boxes on) gets 1 + the index of its eight boxes in bytes 88..91.
+inline void outward_f32(const double* box6, float* out6);
+inline void build_leaf_boxes(const rt_node* nodes, size_t n_nodes, const double* tris, const double* quads,
+                             std::vector<uint32_t>& rec, std::vector<float>& out) {
+    const double inf = std::numeric_limits<double>::infinity();
+    for (size_t i = 0; i + 1 < n_nodes; ++i) {
+        const rt_node& b = nodes[i];
+        const rt_node& n = nodes[i + 1];
+        if (b.kind != RT_NODE_BVH || b.skip != i + 2 || n.chain != b.chain) continue;
+        if ((n.kind != RT_NODE_TRIANGLES && n.kind != RT_NODE_QUADS) || n.count < 3 || n.count > 16) continue;
+        const double* recs = n.kind == RT_NODE_TRIANGLES ? tris : quads;
+        const uint32_t leaf = (uint32_t)(out.size() / 48);
+        for (uint32_t j = 0; j < 8; ++j) {
+            double box[6] = {inf, -inf, inf, -inf, inf, -inf};  // empty: fails every test
+            for (uint32_t k = 2 * j; k < std::min(2 * j + 2, n.count); ++k) {
+                const double* r = recs + 16 * (size_t)(n.first + k);  // n(3) d q(3) u(3) v(3) w(3)
+                for (int c = 0; c < 3; ++c) {
+                    const double q = r[4 + c], u = r[7 + c], v = r[10 + c];
+                    const double corner[4] = {q, q + u, q + v, n.kind == RT_NODE_QUADS ? q + u + v : q};
+                    for (double x : corner) {
+                        if (!(x == x)) { box[2 * c] = -inf; box[2 * c + 1] = inf; continue; }  // NaN: no culling
+                        box[2 * c] = std::min(box[2 * c], x - 1e-5 * (1.0 + std::fabs(x)));
+                        box[2 * c + 1] = std::max(box[2 * c + 1], x + 1e-5 * (1.0 + std::fabs(x)));
+                    }
+                }
+            }
+            float f[6];
+            outward_f32(box, f);
+            out.insert(out.end(), f, f + 6);
+        }
+        rec[32 * i + 22] = leaf + 1u;
+    }
+}
 
 // A box (x, y, z: start, end) as f32, every bound rounded away from the inside.
 inline void outward_f32(const double* box6, float* out6) {

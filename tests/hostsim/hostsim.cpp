@@ -23,6 +23,9 @@ struct sim_scene {  // host pointers to the arrays of a flattened scene
 };
 
 static std::vector<uint32_t> g_records, g_quad_axis;
+static std::vector<float> g_leaf_boxes;
+static int use_leaf_boxes = 1;  // 0: BVH leaves without cull boxes per pair of primitives
+extern "C" void sim_set_leaf_boxes(int on) { use_leaf_boxes = on; }
 static int use_cull = 1;      // 0: every cull box switched off, as under RT_FLAG_NO_CULL
 static int use_one_pass = 1;  // 0: media always take their two boundary hits in two passes
 static SigInfo g_sig;
@@ -38,6 +41,10 @@ static DScene to_dscene(const sim_scene* s) {
     }
     std::memset(&g_sig, 0, sizeof g_sig);
     g_sig.n = (uint32_t)sig.size();
+    g_leaf_boxes.clear();
+    if (use_cull && use_leaf_boxes) build_leaf_boxes(s->nodes, (size_t)s->n_nodes, s->tris, s->quads, g_records, g_leaf_boxes);
+    g_leaf_boxes.resize(g_leaf_boxes.size() + 48, 0.0f);
+    d.leaf_sub = g_leaf_boxes.data();
     d.nodes = reinterpret_cast<const uint4*>(g_records.data()); d.n_nodes = (uint32_t)s->n_nodes; d.spheres = s->spheres; d.quads = s->quads;
     d.tris = s->tris; d.quadrics = s->quadrics; d.sphere_mat = s->sphere_mat; d.sphere_id = s->sphere_id;
     d.quad_mat = s->quad_mat; d.quad_id = s->quad_id; d.tri_mat = s->tri_mat; d.tri_id = s->tri_id;
@@ -85,6 +92,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
                 if (ln.state == RT_ST_RUN) lane_prim_step<true>(S, ln, tally);
                 if (ln.state == RT_ST_MEDIUM) lane_medium_step<true>(S, src, ln, L, rng, tally);
                 if (ln.state == RT_ST_CHAIN) lane_chain_step(S, src, ln);
+                if (ln.state == RT_ST_SUB) lane_sub_step<true>(S, ln, tally);
             }
             b = ln.best;
         } else if (mode == 1) {
