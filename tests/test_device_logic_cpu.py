@@ -76,6 +76,34 @@ def test_cull_boxes_save_work(pairs, cfg):
         assert with_cull["prim_tests"] < 0.7 * base["prim_tests"]
 
 
+def test_leaf_boxes_cut_triangle_tests(pairs):
+    """BVH leaves of the two meshes in cornell_model carry a cull box per pair of triangles; the per-lane state
+    machine tests the eight boxes of a leaf in one step and visits only the pairs whose box the ray can touch.  Same
+    hits as the oracle bit for bit, well under half of the primitive tests, and with the cull boxes switched off
+    exactly the oracle's."""
+    hs, os_, sim = pairs("C4")
+    L = helpers._sim_lib()
+    _, oc = cameras(hs)
+    o, d, rng3 = path_rays(os_, oc, 1500, 1)
+    want = os_.builder.intersect(o, d, 0.001, np.inf, rng3)
+    L.sim_set_walk_mode(2)
+    try:
+        got = sim.intersect(o, d, 0.001, np.inf, rng3)
+        L.sim_set_leaf_boxes(0)
+        plain = sim.intersect(o, d, 0.001, np.inf, rng3)
+        L.sim_set_leaf_boxes(1)
+        sim.set_cull(False)
+        exact = sim.intersect(o, d, 0.001, np.inf, rng3)
+    finally:
+        sim.set_cull(True)
+        L.sim_set_leaf_boxes(1)
+        L.sim_set_walk_mode(0)
+    for name, r in (("leaf boxes", got), ("no leaf boxes", plain), ("no culling", exact)):
+        assert_hits_equal(r, want, exact=True, what=name)
+    assert exact["counters"]["prim_tests"] == want["counters"]["prim_tests"]
+    assert got["counters"]["prim_tests"] < 0.6 * plain["counters"]["prim_tests"] < want["counters"]["prim_tests"]
+
+
 def test_ray_signatures_prune_the_lockstep_walk(pairs):
     """A lockstep wavefront whose rays all have a signature bit clear walks a copy of the tree without that
     entry's subtree (here: a "wavefront" of one ray).  Same hits as the oracle, and on cornell_smoke, whose two
