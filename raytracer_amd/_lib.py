@@ -53,9 +53,9 @@ class rt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64),
                 ("cull_tests", C.c_uint64), ("prim_bytes", C.c_uint64), ("prim_flops", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_traverse", C.c_double), ("ms_shade", C.c_double),
-                ("ms_paths", C.c_double), ("ms_bounce", C.c_double), ("traverse_launches", C.c_uint32),
+                ("ms_paths", C.c_double), ("ms_bounce", C.c_double), ("ms_finish", C.c_double), ("traverse_launches", C.c_uint32),
                 ("path_launches", C.c_uint32), ("bounce_launches", C.c_uint32), ("bounces", C.c_uint32),
-                ("lockstep", C.c_uint32), ("reserved", C.c_uint32)]
+                ("lockstep", C.c_uint32), ("finish_launches", C.c_uint32)]
 
 
 RT_FLAG_COUNTERS = 1

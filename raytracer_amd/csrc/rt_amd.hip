@@ -598,6 +598,83 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     }
 }
 
+// The tail of a render over a tree WITHOUT BVH entries: once few rays are left and no batch remains to be generated, a
+// launch per bounce costs its latency and little else (dozens of launches of some tens of microseconds).  This kernel
+// takes the rays that are left, one per lane, and follows each path to its end -- the same walk, material code and
+// shared rejection loop as k_bounce_lockstep, bounce after bounce, no queue written.  counters[0] += rays traced,
+// counters[1] = max(iteration index after the last bounce of any path).
+#define RT_FINISH_MAX (1u << 17)  // rays in flight (upper bound) from which the tail is taken in one launch
+template <int MEDIA, bool PLAIN>
+__global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish_lockstep(
+    DScene S, uint64_t seed, Segs segs, Queue q, double* lum_r, double* lum_g, double* lum_b, double bgr, double bgg,
+    double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters) {
+    uint32_t n;
+    const uint32_t idx = seg_slot(segs, n);
+    Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    bool alive = idx < n;
+    V3 o = mk(0, 0, 0), d = mk(1, 1, 1), beta = mk(0, 0, 0);
+    uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
+    if (alive) {
+        o = mk(q.ox[idx], q.oy[idx], q.oz[idx]); d = mk(q.dx[idx], q.dy[idx], q.dz[idx]);
+        beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
+        pix = q.pix[idx]; smp = q.smp[idx]; slot = q.slot[idx]; born = q.born[idx]; ctr = q.ctr[idx];
+    }
+    uint32_t rays = 0, last = 0;
+    for (uint32_t it = iter; __ballot(alive) != 0ull; ++it) {
+        bool hit = false;
+        Rec rec;
+        rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
+        rt_material m;
+        m.kind = RT_MAT_DIFFUSE_LIGHT; m.texture = 0; m.param = 0; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0;
+        V3 lum = mk(0, 0, 0);
+        bool ended = false;
+        if (alive) {
+            RayVal src; src.o = o; src.d = d;
+            const Ray w = src.world();
+            rays++;
+            last = it + 1u;
+            RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32); rp.pixel = pix; rp.sample = smp; rp.ctr = ctr;
+            const Best b = closest_hit<false, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
+            ctr = rp.ctr;
+            if (b.ref == RT_NO_HIT) {
+                lum = beta * mk(bgr, bgg, bgb);
+                ended = true;
+            } else {
+                rec = finalize<false, PLAIN>(S, w, b);
+                m = S.mats[rec.mat];
+                hit = true;
+            }
+        }
+        const V3 ruv = wave_unit_vector(hit && scatter_wants_unit_vector<PLAIN>(m), (uint32_t)seed, (uint32_t)(seed >> 32),
+                                        pix, smp, ctr);
+        if (hit) {
+            Rng rng = rng_make(seed, pix, smp, ctr);
+            V3 nd, att, emit;
+            if (!scatter_given<PLAIN>(S, m, d, rec, rng, ruv, nd, att, emit)) {
+                lum = beta * emit;
+                ended = true;
+            } else if (it - born + 1u == max_depth) {
+                ended = true;  // the scattered ray would be traced with depth 0: black (camera.rs:350-352)
+            } else {
+                beta = beta * att;
+                o = rec.p;
+                d = nd;
+                ctr = rng.ctr;
+            }
+        }
+        if (ended) { lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z; alive = false; }
+    }
+    unsigned long long r = rays;
+    uint32_t lt = last;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        const uint32_t other = __shfl_down(lt, off);
+        lt = lt > other ? lt : other;
+    }
+    if ((threadIdx.x & 63u) == 0u && r != 0ull) { atomicAdd(&counters[0], r); atomicMax(&counters[1], (unsigned long long)lt); }
+}
+
 // film[pix] += lum[s][pix] for s = 0.. in sample order: the running sum of camera.rs:258-264 (Point3::sum folds
 // from -0.0, point3/mod.rs:96-109; the host initialises the film with -0.0).
 __global__ void k_film_accumulate(const double* lum_r, const double* lum_g, const double* lum_b, uint32_t npix,
@@ -1366,6 +1443,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         Queue qin = s->qa, qout = s->qb;
         uint32_t injected = 0, accumulated = 0, consumed = 0, last_busy = 0;
         uint32_t known_out = 0;                // exact number of rays iteration `consumed - 1` left behind
+        bool finished = false;                 // the tail went to k_finish_lockstep
         HIP_TRY(hipMemsetAsync(s->d_ring, 0, RT_RING_WORDS * 4, sm));  // nothing waits before iteration 0
         auto consume = [&]() -> int {          // read what iteration `consumed` left behind
             const uint32_t j = consumed, r = j % RT_RING, rn = (j + 1u) % RT_RING;
@@ -1422,8 +1500,35 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                 if (injected == nbatches) break;  // nothing in flight and nothing left to generate
                 return fail(RT_ERR_STATE, "queue empty with batches left");
             }
-            hist.push_back({fresh, upper_in});
             const uint32_t r = iter % RT_RING, rn = (iter + 1u) % RT_RING;
+            if (bounce && injected == nbatches && upper_in <= RT_FINISH_MAX) {
+                // the tail: every path that is left is followed to its end in one launch
+                DScene d = s->d;
+                if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
+                Segs segs;
+                std::memset(&segs, 0, sizeof segs);
+                segs.in_count = s->d_ring + r * RT_RING_WORDS;
+                segs.nclass = nclass;
+                segs.stride = (uint32_t)qcap;
+                segs.fresh = fresh;
+                const uint32_t blocks = (upper_in + BOUNCE_BLOCK - 1) / BOUNCE_BLOCK + nclass + 1u;
+                HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));
+                HIP_TRY(hipEventRecord(s->ev[1], sm));
+#define FINISH_ARGS d, o->seed, segs, qin, s->lum_r, s->lum_g, s->lum_b, o->background[0], o->background[1], \
+                    o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8)
+#define FINISH(M, P) hipLaunchKernelGGL((k_finish_lockstep<M, P>), dim3(blocks), dim3(BOUNCE_BLOCK), \
+                                        levels_lds(s, BOUNCE_BLOCK), sm, FINISH_ARGS)
+                if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(RT_MEDIA_NONE, true); else FINISH(RT_MEDIA_NONE, false); }
+                else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) FINISH(RT_MEDIA_FLAT, true); else FINISH(RT_MEDIA_FLAT, false); }
+                else { if (s->plain) FINISH(RT_MEDIA_ANY, true); else FINISH(RT_MEDIA_ANY, false); }
+#undef FINISH
+#undef FINISH_ARGS
+                HIP_TRY(hipEventRecord(s->ev[2], sm));
+                HIP_TRY(hipGetLastError());
+                finished = true;
+                break;
+            }
+            hist.push_back({fresh, upper_in});
             uint32_t* const out_count = s->d_ring + rn * RT_RING_WORDS;
             Segs segs;
             std::memset(&segs, 0, sizeof segs);
@@ -1466,7 +1571,19 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             std::swap(qin, qout);
         }
         while (consumed < hist.size()) if ((rc = consume())) return rc;
-        if (known_out != 0) return fail(RT_ERR_STATE, "rays left in the queue");
+        if (finished) {
+            unsigned long long h[2];
+            HIP_TRY(hipMemcpyAsync(h, s->d_count + 8, 16, hipMemcpyDeviceToHost, sm));
+            HIP_TRY(hipStreamSynchronize(sm));
+            st.rays += h[0];
+            last_busy = std::max(last_busy, (uint32_t)h[1]);
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+            st.ms_finish += ms;
+            st.finish_launches++;
+        } else if (known_out != 0) {
+            return fail(RT_ERR_STATE, "rays left in the queue");
+        }
         while (accumulated < injected) {  // (a render of depth 0 generates nothing; everything else was added above)
             const uint32_t slot0 = (uint32_t)((accumulated % nslots) * bsize);
             hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + slot0,
@@ -1586,7 +1703,8 @@ int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, 
             t.cull_tests += a.cull_tests; t.prim_bytes += a.prim_bytes; t.prim_flops += a.prim_flops;
             t.ms_total = std::max(t.ms_total, a.ms_total); t.ms_traverse = std::max(t.ms_traverse, a.ms_traverse);
             t.ms_shade = std::max(t.ms_shade, a.ms_shade); t.ms_paths = std::max(t.ms_paths, a.ms_paths);
-            t.ms_bounce = std::max(t.ms_bounce, a.ms_bounce);
+            t.ms_bounce = std::max(t.ms_bounce, a.ms_bounce); t.ms_finish = std::max(t.ms_finish, a.ms_finish);
+            t.finish_launches += a.finish_launches;
             t.traverse_launches += a.traverse_launches; t.path_launches += a.path_launches;
             t.bounce_launches += a.bounce_launches;
             t.bounces = std::max(t.bounces, a.bounces); t.lockstep = a.lockstep;
