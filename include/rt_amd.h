@@ -56,9 +56,7 @@ typedef struct rt_texture {
     uint32_t kind;
     uint32_t a;
     uint32_t b;
-    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep (+ k_finish_lockstep) /
-                          k_traverse_lockstep / k_paths_lockstep, otherwise k_traverse_persistent */
-    uint32_t finish_launches;
+    uint32_t reserved;
     double color[3];
     double scale;
 } rt_texture;
@@ -70,9 +68,7 @@ enum rt_xform_kind {
 };
 typedef struct rt_xform_op {
     uint32_t kind;
-    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep (+ k_finish_lockstep) /
-                          k_traverse_lockstep / k_paths_lockstep, otherwise k_traverse_persistent */
-    uint32_t finish_launches;
+    uint32_t reserved;
     double v[3];
 } rt_xform_op;
 /* A chain lists the instance transforms between the world and a node, outermost first.  Chain 0 is empty. */
@@ -170,13 +166,12 @@ typedef struct rt_stats {
     double ms_paths;     /* summed duration of the whole-path launches (scenes without BVH entries) */
     double ms_bounce;    /* summed duration of the bounce launches: traverse, shade and compaction in one kernel
                             (queue-based schedule of scenes without BVH entries) */
-    double ms_finish;    /* duration of the launch that follows the last paths of a scene without BVH entries to their
-                            ends (at most one per call) */
+    double ms_finish;    /* duration of the launch that follows the last paths to their ends (at most one per call) */
     uint32_t traverse_launches;
     uint32_t path_launches;
     uint32_t bounce_launches;
     uint32_t bounces; /* most world.hit calls any one path made */
-    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep (+ k_finish_lockstep) /
+    uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep (+ k_finish) /
                           k_traverse_lockstep / k_paths_lockstep, otherwise k_traverse_persistent */
     uint32_t finish_launches;
 } rt_stats;

@@ -16,12 +16,12 @@ class rt_material(C.Structure):
 
 
 class rt_texture(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("lockstep", C.c_uint32),
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("reserved", C.c_uint32),
                 ("color", C.c_double * 3), ("scale", C.c_double)]
 
 
 class rt_xform_op(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("lockstep", C.c_uint32), ("v", C.c_double * 3)]
+    _fields_ = [("kind", C.c_uint32), ("reserved", C.c_uint32), ("v", C.c_double * 3)]
 
 
 class rt_chain(C.Structure):

@@ -598,14 +598,16 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     }
 }
 
-// The tail of a render over a tree WITHOUT BVH entries: once few rays are left and no batch remains to be generated, a
-// launch per bounce costs its latency and little else (dozens of launches of some tens of microseconds).  This kernel
-// takes the rays that are left, one per lane, and follows each path to its end -- the same walk, material code and
-// shared rejection loop as k_bounce_lockstep, bounce after bounce, no queue written.  counters[0] += rays traced,
+// The tail of a render: once few rays are left and no batch remains to be generated, a launch (or two) per bounce costs
+// its latency and little else -- dozens of launches of some tens of microseconds.  This kernel takes the rays that
+// are left, one per lane, and follows each path to its end: the same material code and shared rejection loop as the
+// bounce and shade kernels, bounce after bounce, no queue written; the walk is the lockstep one for trees without BVH
+// entries and the plain per-lane walk (the one k_trace_samples uses) for trees with them -- with so few rays it is
+// the length of the longest path that counts, not how well the lanes are used.  counters[0] += rays traced,
 // counters[1] = max(iteration index after the last bounce of any path).
 #define RT_FINISH_MAX (1u << 17)  // rays in flight (upper bound) from which the tail is taken in one launch
-template <int MEDIA, bool PLAIN>
-__global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish_lockstep(
+template <bool LOCKSTEP, int MEDIA, bool PLAIN>
+__global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
     DScene S, uint64_t seed, Segs segs, Queue q, double* lum_r, double* lum_g, double* lum_b, double bgr, double bgg,
     double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters) {
     uint32_t n;
@@ -635,7 +637,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish_lockstep(
             rays++;
             last = it + 1u;
             RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32); rp.pixel = pix; rp.sample = smp; rp.ctr = ctr;
-            const Best b = closest_hit<false, true, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
+            const Best b = closest_hit<false, LOCKSTEP, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
             ctr = rp.ctr;
             if (b.ref == RT_NO_HIT) {
                 lum = beta * mk(bgr, bgg, bgb);
@@ -1443,7 +1445,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         Queue qin = s->qa, qout = s->qb;
         uint32_t injected = 0, accumulated = 0, consumed = 0, last_busy = 0;
         uint32_t known_out = 0;                // exact number of rays iteration `consumed - 1` left behind
-        bool finished = false;                 // the tail went to k_finish_lockstep
+        bool finished = false;                 // the tail went to k_finish
         HIP_TRY(hipMemsetAsync(s->d_ring, 0, RT_RING_WORDS * 4, sm));  // nothing waits before iteration 0
         auto consume = [&]() -> int {          // read what iteration `consumed` left behind
             const uint32_t j = consumed, r = j % RT_RING, rn = (j + 1u) % RT_RING;
@@ -1501,7 +1503,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                 return fail(RT_ERR_STATE, "queue empty with batches left");
             }
             const uint32_t r = iter % RT_RING, rn = (iter + 1u) % RT_RING;
-            if (bounce && injected == nbatches && upper_in <= RT_FINISH_MAX) {
+            if ((bounce || (!lockstep && !count)) && injected == nbatches && upper_in <= RT_FINISH_MAX) {
                 // the tail: every path that is left is followed to its end in one launch
                 DScene d = s->d;
                 if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
@@ -1516,11 +1518,12 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                 HIP_TRY(hipEventRecord(s->ev[1], sm));
 #define FINISH_ARGS d, o->seed, segs, qin, s->lum_r, s->lum_g, s->lum_b, o->background[0], o->background[1], \
                     o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8)
-#define FINISH(M, P) hipLaunchKernelGGL((k_finish_lockstep<M, P>), dim3(blocks), dim3(BOUNCE_BLOCK), \
-                                        levels_lds(s, BOUNCE_BLOCK), sm, FINISH_ARGS)
-                if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(RT_MEDIA_NONE, true); else FINISH(RT_MEDIA_NONE, false); }
-                else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) FINISH(RT_MEDIA_FLAT, true); else FINISH(RT_MEDIA_FLAT, false); }
-                else { if (s->plain) FINISH(RT_MEDIA_ANY, true); else FINISH(RT_MEDIA_ANY, false); }
+#define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(BOUNCE_BLOCK), \
+                                            levels_lds(s, BOUNCE_BLOCK), sm, FINISH_ARGS)
+                if (!lockstep) { if (s->plain) FINISH(false, RT_MEDIA_ANY, true); else FINISH(false, RT_MEDIA_ANY, false); }
+                else if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(true, RT_MEDIA_NONE, true); else FINISH(true, RT_MEDIA_NONE, false); }
+                else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) FINISH(true, RT_MEDIA_FLAT, true); else FINISH(true, RT_MEDIA_FLAT, false); }
+                else { if (s->plain) FINISH(true, RT_MEDIA_ANY, true); else FINISH(true, RT_MEDIA_ANY, false); }
 #undef FINISH
 #undef FINISH_ARGS
                 HIP_TRY(hipEventRecord(s->ev[2], sm));

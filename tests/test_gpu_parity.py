@@ -105,7 +105,7 @@ def test_film_equals_sum_of_samples(gpu_scenes, cfg, schedule):
     no_bvh = cfg in ("C2", "C3")
     assert (stats["path_launches"] > 0) == (schedule == "whole-paths" and no_bvh)
     assert (stats["bounce_launches"] > 0) == (schedule == "queues" and no_bvh)
-    assert stats["finish_launches"] == (1 if schedule == "queues" and no_bvh else 0)  # the tail in one launch
+    assert stats["finish_launches"] == (1 if (schedule == "queues" or not no_bvh) else 0)  # the tail in one launch
     assert sum(stats[k] > 0 for k in ("traverse_launches", "path_launches", "bounce_launches")) == 1
     npix = hc.width * hc.height
     pixel = np.tile(np.arange(npix, dtype=np.uint32), spp)
