@@ -162,6 +162,9 @@ def main():
             kernel = "k_traverse_lockstep" if stats[0]["lockstep"] else "k_traverse_persistent"
             launches, ms_trav, b_kernel = sum(s["traverse_launches"] for s in stats), \
                 sum(s["ms_traverse"] for s in stats), b_trav
+        if launches == 0:  # so small a workload that the tail kernel took all of it
+            kernel = "k_finish"
+            launches, ms_trav, b_kernel = sum(s["finish_launches"] for s in stats), sum(s["ms_finish"] for s in stats), b_ray
         avg_launch_ms = ms_trav / launches
         achieved = (rays_local / launches) * b_kernel / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
