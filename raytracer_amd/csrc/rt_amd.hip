@@ -1520,7 +1520,8 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                     o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8)
 #define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(BOUNCE_BLOCK), \
                                             levels_lds(s, BOUNCE_BLOCK), sm, FINISH_ARGS)
-                if (!lockstep) { if (s->plain) FINISH(false, RT_MEDIA_ANY, true); else FINISH(false, RT_MEDIA_ANY, false); }
+                if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
+                else if (!lockstep) { if (s->plain) FINISH(false, RT_MEDIA_ANY, true); else FINISH(false, RT_MEDIA_ANY, false); }
                 else if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(true, RT_MEDIA_NONE, true); else FINISH(true, RT_MEDIA_NONE, false); }
                 else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) FINISH(true, RT_MEDIA_FLAT, true); else FINISH(true, RT_MEDIA_FLAT, false); }
                 else { if (s->plain) FINISH(true, RT_MEDIA_ANY, true); else FINISH(true, RT_MEDIA_ANY, false); }
