@@ -9,10 +9,10 @@ HOSTFLAGS := -O2 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wall
 
 all: $(CSRC)/librt_amd.so $(CSRC)/librt_host.so oracle
 
-$(CSRC)/librt_amd.so: $(CSRC)/rt_amd.hip $(CSRC)/rt_core.h include/rt_amd.h
+$(CSRC)/librt_amd.so: $(CSRC)/rt_amd.hip $(wildcard $(CSRC)/*.h) include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/rt_amd.hip
 
-$(CSRC)/librt_host.so: $(wildcard $(CSRC)/host/*.cpp) $(wildcard $(CSRC)/host/*.h) include/rt_amd.h include/rt_host.h $(CSRC)/librt_amd.so
+$(CSRC)/librt_host.so: $(wildcard $(CSRC)/host/*.cpp) $(wildcard $(CSRC)/host/*.h) $(wildcard $(CSRC)/*.h) include/rt_host.hpp include/rt_amd.h include/rt_host.h $(CSRC)/librt_amd.so
 	$(CXX) $(HOSTFLAGS) -o $@ $(wildcard $(CSRC)/host/*.cpp) -L$(CSRC) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
 
 oracle:

@@ -141,7 +141,14 @@ struct TravArgs {
     const double* tmax;     // nullable
     uint32_t chunk;         // rays a wavefront of the persistent kernel takes per hand-out
     Segs segs;              // where the rays are
+    uint32_t first, end;    // the stretch of top-level entries this launch walks (the whole tree: 0, n_nodes)
+    uint32_t resume;        // 1: go on from the closest hit in `hb` (what the stretches before this one have left)
 };
+__device__ __forceinline__ Best trav_best_setup(const TravArgs& a, uint32_t idx) {
+    Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
+    if (a.resume) { b.t = a.hb.t[idx]; b.ref = a.hb.ref[idx]; b.chain = a.hb.chain[idx]; }
+    return b;
+}
 __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, RngPos& rng, double& tmin, double& tmax) {
     rng.k0 = (uint32_t)a.seed; rng.k1 = (uint32_t)(a.seed >> 32);
     rng.pixel = a.q.pix[idx]; rng.sample = a.q.smp[idx];
@@ -167,15 +174,16 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     // with sorted queues the wavefront walks the copy of the tree without everything its rays' signatures rule out
-    uint32_t first = 0u;
-    if (a.segs.in_count != nullptr) first = tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
+    uint32_t first = a.first;
+    if (a.segs.in_count != nullptr) first += tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
     if (idx < n) {
         RngPos rng;
         double tmin, tmax;
         trav_ray_setup(a, idx, rng, tmin, tmax);
         RaySoA src;
         src.ox = a.q.ox; src.oy = a.q.oy; src.oz = a.q.oz; src.dx = a.q.dx; src.dy = a.q.dy; src.dz = a.q.dz; src.idx = idx;
-        Best b = closest_hit<COUNT, true, MEDIA>(S, src, tmin, tmax, L, rng, tally, first);
+        Best b = closest_hit_range<COUNT, true, MEDIA>(S, src, tmin, tmax, L, rng, tally, first, first + (a.end - a.first),
+                                                       trav_best_setup(a, idx));
         a.hb.t[idx] = b.t; a.hb.ref[idx] = b.ref; a.hb.chain[idx] = b.chain;
         a.q.ctr[idx] = rng.ctr;
     }
@@ -246,7 +254,8 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
                             src.idx = idx;
                             double tmin, tmax;
                             trav_ray_setup(a, idx, rng, tmin, tmax);
-                            lane_begin(ln, src, tmin, tmax, L);
+                            lane_begin(ln, src, tmin, tmax, L, a.first);
+                            ln.best = trav_best_setup(a, idx);
                         }
                     }
                     const uint32_t want = pool_next + (uint32_t)__popcll(mask);
@@ -772,6 +781,11 @@ struct rt_scene {
     int device = -1;
     uint32_t levels = 0;  // interval slots per lane the walk needs
     bool has_bvh = false; // selects the traverse kernel: lockstep (no BVH entries) or persistent
+    // A tree with BVH entries is walked in stretches of whole top-level entries: those without a BVH entry below them
+    // (every ray does the same work there) by the lockstep kernel, the others by the persistent one; the closest hit
+    // so far travels from one launch to the next in the hit buffer.
+    struct Stretch { uint32_t first, end; bool lockstep; };
+    std::vector<Stretch> stretches;
     int media_mode = RT_MEDIA_NONE;  // RT_MEDIA_FLAT when every medium's boundary is plain primitives, else RT_MEDIA_ANY
     bool plain = false;   // only Lambertian / DiffuseLight / Isotropic over SolidColor: selects the lean shade kernel
     uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
@@ -1028,6 +1042,18 @@ static int validate(rt_scene* s) {
         s->plain = s->plain && kind_ok && s->texs[m.texture].kind == RT_TEX_SOLID;
     }
     if (s->levels > RT_MAX_LEVELS) return fail(RT_ERR_LIMIT, "scene needs %u levels, limit %d", s->levels, RT_MAX_LEVELS);
+    s->stretches.clear();
+    for (uint32_t i = 0; i < nn;) {
+        const rt_node& n = s->nodes[i];
+        const uint32_t next = (n.kind == RT_NODE_BVH || n.kind == RT_NODE_MEDIUM || n.kind == RT_NODE_CULL) ? n.skip : i + 1u;
+        bool uniform = true;
+        for (uint32_t j = i; j < next; ++j) uniform = uniform && s->nodes[j].kind != RT_NODE_BVH;
+        if (!s->has_bvh) uniform = true;
+        if (!s->stretches.empty() && s->stretches.back().lockstep == uniform) s->stretches.back().end = next;
+        else s->stretches.push_back({i, next, uniform});
+        i = next;
+    }
+    if (s->stretches.empty()) s->stretches.push_back({0u, 0u, true});
     return RT_OK;
 }
 
@@ -1189,32 +1215,38 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 
 // One traverse+intersect launch over the rays of `a` on the scene's stream.
 // `n_upper`: no fewer rays than the launch will find (it sizes the grid; the kernels read the true numbers themselves).
-static int launch_traverse(rt_scene* s, const TravArgs& a, bool count, bool nocull, uint32_t n_upper) {
+static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool nocull, uint32_t n_upper) {
     const size_t lds = levels_lds(s, TRAV_BLOCK);
     DScene d = s->d;
     if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
     // every stretch of the queue starts a workgroup of its own
-    const uint32_t waves = (n_upper + TRAV_BLOCK - 1) / TRAV_BLOCK + (a.segs.in_count ? a.segs.nclass + 1u : 0u);
-    if (!s->has_bvh) {
+    const uint32_t waves = (n_upper + TRAV_BLOCK - 1) / TRAV_BLOCK + (a_.segs.in_count ? a_.segs.nclass + 1u : 0u);
+    for (size_t k = 0; k < s->stretches.size(); ++k) {
+        const rt_scene::Stretch& st = s->stretches[k];
+        TravArgs a = a_;
+        a.first = st.first; a.end = st.end; a.resume = k > 0 ? 1u : 0u;
+        if (st.lockstep) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
-        if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
-        else if (s->media_mode == RT_MEDIA_NONE) LOCKSTEP(false, RT_MEDIA_NONE);
-        else if (s->media_mode == RT_MEDIA_FLAT) LOCKSTEP(false, RT_MEDIA_FLAT);
-        else LOCKSTEP(false, RT_MEDIA_ANY);
+            if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
+            else if (s->media_mode == RT_MEDIA_NONE) LOCKSTEP(false, RT_MEDIA_NONE);
+            else if (s->media_mode == RT_MEDIA_FLAT) LOCKSTEP(false, RT_MEDIA_FLAT);
+            else LOCKSTEP(false, RT_MEDIA_ANY);
 #undef LOCKSTEP
-    } else {
-        HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
-        const uint32_t grid = std::min(waves, s->persist_waves);
-        // RT_CHUNK rays per hand-out when there is plenty of work; fewer (down to one wavefront's worth) when the
-        // launch is small, so that the rays spread over the whole device instead of queueing up behind a few waves
-        TravArgs sized = a;
-        sized.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->persist_waves) + 63u) / 64u * 64u));
-#define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, d, sized, s->d_count + 4, s->d_tallies)
-        if (count) PERSIST(true, RT_MEDIA_ANY);
-        else if (s->media_mode == RT_MEDIA_NONE) PERSIST(false, RT_MEDIA_NONE);
-        else if (s->media_mode == RT_MEDIA_FLAT) PERSIST(false, RT_MEDIA_FLAT);
-        else PERSIST(false, RT_MEDIA_ANY);
+        } else {
+            HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
+            const uint32_t grid = std::min(waves, s->persist_waves);
+            // RT_CHUNK rays per hand-out when there is plenty of work; fewer (down to one wavefront's worth) when the
+            // launch is small, so that the rays spread over the whole device instead of queueing up behind a few waves
+            a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->persist_waves) + 63u) / 64u * 64u));
+            DScene dp = d;
+            dp.n_nodes = st.end;  // where the per-lane walk stops
+#define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, dp, a, s->d_count + 4, s->d_tallies)
+            if (count) PERSIST(true, RT_MEDIA_ANY);
+            else if (s->media_mode == RT_MEDIA_NONE) PERSIST(false, RT_MEDIA_NONE);
+            else if (s->media_mode == RT_MEDIA_FLAT) PERSIST(false, RT_MEDIA_FLAT);
+            else PERSIST(false, RT_MEDIA_ANY);
 #undef PERSIST
+        }
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;

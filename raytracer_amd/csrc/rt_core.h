@@ -952,6 +952,17 @@ RT_HD Best closest_hit(const DScene& S, const Src& src, double tmin, double tmax
     walk<MEDIA, COUNT, LOCKSTEP>(S, src, first, first + S.n_nodes, L, rng, best, cur, cur_chain, tally);
     return best;
 }
+// The same over entries [first, end) of the top level only, going on from `best` (what the entries before `first`
+// have left): the reference's list scan (hittable_list.rs:88-102) cut into stretches.
+template <bool COUNT, bool LOCKSTEP, int MEDIA = RT_MEDIA_ANY, class Src>
+RT_HD Best closest_hit_range(const DScene& S, const Src& src, double tmin, double tmax, const Levels& L, RngPos& rng,
+                             Tally& tally, uint32_t first, uint32_t end, Best best) {
+    lv_set(L, 0u, tmin, tmax);
+    Ray cur = src.world();
+    uint32_t cur_chain = 0;
+    walk<MEDIA, COUNT, LOCKSTEP>(S, src, first, end, L, rng, best, cur, cur_chain, tally);
+    return best;
+}
 
 // The same walk as a per-lane state machine that does one BVH entry and one primitive test per step, for the
 // kernel that keeps every lane busy by handing it a new ray as soon as its ray is finished.
@@ -973,11 +984,11 @@ struct Lane {
     uint32_t state;
 };
 template <class Src>
-RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const Levels& L) {
+RT_HD void lane_begin(Lane& ln, const Src& src, double tmin, double tmax, const Levels& L, uint32_t first = 0u) {
     ln.cur = src.world();
     ray_need_inv(ln.cur);
     ln.cur_chain = 0;
-    ln.i = 0;
+    ln.i = first;
     ln.k = ln.kend = 0; ln.kind = 0;
     ln.s = tmin; ln.e = tmax;
     ln.best.t = RT_INF; ln.best.ref = RT_NO_HIT; ln.best.chain = 0;
