@@ -16,6 +16,7 @@
 
 #include "rt_core.h"
 #include "rt_records.h"
+#include "rt_wide.h"
 
 using namespace rt;
 
@@ -60,27 +61,66 @@ struct HitBuf {
 
 extern __shared__ double2 g_levels[];
 
+// Work lists of the gated launches (trees with BVH entries): list b holds the queue slots of the rays whose gate bit b
+// is set, in no particular order; its length is counted in word RT_COUNT_STRIDE * (4 + b) of a counter set.
+#define RT_COUNT_STRIDE 64u  // counters sit 256 bytes apart: their atomics go to different cache lines
+struct Gates {
+    const GateInfo* info;  // what the bits are made of
+    uint32_t* lists;       // list b starts at lists + b * stride
+    uint32_t stride, n;    // n = 0: no gates
+};
+// Appends slot `dst` of every `alive` thread to the lists its ray (o, d) belongs in: ballot + prefix count per wave and
+// list, one atomic per workgroup and list.  Called by all threads of a 256-thread workgroup together.
+__device__ __forceinline__ void gates_append(const Gates& G, bool alive, uint32_t dst, V3 o, V3 d, uint32_t* counts) {
+    __shared__ uint32_t g_wave[4][RT_MAX_GATES];
+    __shared__ uint32_t g_base[RT_MAX_GATES];
+    if (G.n == 0u) return;
+    const uint32_t bits = alive ? ray_gates(*G.info, o, d) : 0u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t b = 0; b < G.n; ++b) {
+        const unsigned long long mask = __ballot((bits >> b) & 1u);
+        if (lane == 0) g_wave[wave][b] = (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+    if (threadIdx.x < G.n) {
+        uint32_t tot = 0;
+        for (int k = 0; k < 4; ++k) { const uint32_t c = g_wave[k][threadIdx.x]; g_wave[k][threadIdx.x] = tot; tot += c; }
+        g_base[threadIdx.x] = tot ? atomicAdd(counts + RT_COUNT_STRIDE * (4u + threadIdx.x), tot) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t b = 0; b < G.n; ++b) {
+        const unsigned long long mask = __ballot((bits >> b) & 1u);
+        if ((bits >> b) & 1u)
+            G.lists[(size_t)b * G.stride + g_base[b] + g_wave[wave][b] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = dst;
+    }
+}
+
 // Camera::get_ray (camera.rs:479-492) for one batch of `nsamples` consecutive samples of every pixel, appended to
 // the queue at `base`.  Batch-local path j = s_local * npix + pixel keeps primary rays of neighbouring pixels in
-// neighbouring lanes.
+// neighbouring lanes.  With gates the new rays also go into their work lists and start from "no hit" in `hb`.
 __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, rt_camera cam, uint64_t seed, uint32_t npix, uint32_t sample0,
-                                                 uint32_t n, uint32_t base, uint32_t slot0, uint32_t iter, Queue q) {
+                                                 uint32_t n, uint32_t base, uint32_t slot0, uint32_t iter, Queue q,
+                                                 Gates gates, HitBuf hb, uint32_t* counts) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    uint32_t pixel = j % npix, s_local = j / npix;
-    Rng rng = rng_make(seed, pixel, sample0 + s_local, 0u);
-    V3 o, d;
-    camera_ray(cam, pixel % cam.width, pixel / cam.width, rng, o, d);
-    uint32_t idx = base + j;
-    q.ox[idx] = o.x; q.oy[idx] = o.y; q.oz[idx] = o.z;
-    q.dx[idx] = d.x; q.dy[idx] = d.y; q.dz[idx] = d.z;
-    q.br[idx] = 1.0; q.bg[idx] = 1.0; q.bb[idx] = 1.0;
-    q.pix[idx] = pixel;
-    q.smp[idx] = sample0 + s_local;
-    q.slot[idx] = slot0 + j;
-    q.born[idx] = iter;
-    q.ctr[idx] = rng.ctr;
-    q.sig[idx] = ray_signature(*Gp, o, d);
+    const bool alive = j < n;
+    V3 o = mk(0, 0, 0), d = mk(1, 1, 1);
+    const uint32_t idx = base + j;
+    if (alive) {
+        uint32_t pixel = j % npix, s_local = j / npix;
+        Rng rng = rng_make(seed, pixel, sample0 + s_local, 0u);
+        camera_ray(cam, pixel % cam.width, pixel / cam.width, rng, o, d);
+        q.ox[idx] = o.x; q.oy[idx] = o.y; q.oz[idx] = o.z;
+        q.dx[idx] = d.x; q.dy[idx] = d.y; q.dz[idx] = d.z;
+        q.br[idx] = 1.0; q.bg[idx] = 1.0; q.bb[idx] = 1.0;
+        q.pix[idx] = pixel;
+        q.smp[idx] = sample0 + s_local;
+        q.slot[idx] = slot0 + j;
+        q.born[idx] = iter;
+        q.ctr[idx] = rng.ctr;
+        q.sig[idx] = ray_signature(*Gp, o, d);
+        if (gates.n) { hb.t[idx] = RT_INF; hb.ref[idx] = RT_NO_HIT; }
+    }
+    gates_append(gates, alive, idx, o, d, counts);
 }
 
 // Where the rays of one launch are.  The queue is a row of regions of `stride` slots: one per signature class (a single
@@ -89,10 +129,9 @@ __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, 
 // RT_COUNT_STRIDE apart, written by the launch before as its `out_count`), so that the host can queue launches
 // without waiting for those numbers; `fresh` it knows.  Every stretch starts a new workgroup (lockstep kernels).
 // in_count = null: one stretch, slots 0 .. n - 1 (caller-supplied batches).
-#define RT_COUNT_STRIDE 64u  // class counters sit 256 bytes apart: their atomics go to different cache lines
 #define RT_RING 4            // counter sets in rotation: the host queues launches RT_LAG iterations ahead of the counts it has read
 #define RT_LAG 2
-#define RT_RING_WORDS (4u * RT_COUNT_STRIDE)
+#define RT_RING_WORDS ((4u + RT_MAX_GATES) * RT_COUNT_STRIDE)  // class counters, then work-list lengths
 struct Segs {
     const uint32_t* __restrict__ in_count;
     uint32_t n;
@@ -143,6 +182,8 @@ struct TravArgs {
     Segs segs;              // where the rays are
     uint32_t first, end;    // the stretch of top-level entries this launch walks (the whole tree: 0, n_nodes)
     uint32_t resume;        // 1: go on from the closest hit in `hb` (what the stretches before this one have left)
+    const uint32_t* wl;       // gated launch: the queue slots to work on and where their number is; null: every ray
+    const uint32_t* wl_count;
 };
 __device__ __forceinline__ Best trav_best_setup(const TravArgs& a, uint32_t idx) {
     Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
@@ -282,6 +323,72 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
         }
     }
     if (COUNT) tally_flush(tally, tallies);
+}
+
+// One top-level BVH entry whose leaves the four-wide tree of rt_wide.h covers: the same scheme as above -- a fixed grid
+// of wavefronts pulls rays, every lane takes a new ray the moment its own is done -- with two kinds of step only, a
+// node of the wide tree (four child boxes, for a leaf's node the reference's narrowing first) or the next primitives of
+// an item.  The ray is taken into the tree's instance chain where it is handed out, by all lanes that take one
+// together; no random numbers are drawn here (no medium below such an entry).
+#define RT_WIDE_STEP_THRESHOLD 24
+#define RT_WIDE_FETCH_THRESHOLD 16
+__global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work) {
+    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t pool_next = 0, pool_end = 0;
+    bool exhausted = false;
+    uint32_t idx = 0xFFFFFFFFu;
+    const uint32_t total = a.wl ? *a.wl_count : seg_total(a.segs);
+    WLane ln;
+    {
+        Best none; none.t = RT_INF; none.ref = RT_NO_HIT; none.chain = 0;
+        wide_begin(ln, S, W, ray_world(mk(0, 0, 0), mk(1, 1, 1)), 0.0, 0.0, none);
+        ln.state = RT_W_DONE;
+    }
+    for (;;) {
+        const bool need = ln.state == RT_W_DONE;
+        const unsigned long long mask = __ballot(need);
+        int n_node = __popcll(__ballot(ln.state == RT_W_NODE));
+        int n_prim = __popcll(__ballot(ln.state == RT_W_PRIM));
+        if (mask != 0ull && (__popcll(mask) >= RT_WIDE_FETCH_THRESHOLD || n_node + n_prim == 0)) {
+            if (need && idx != 0xFFFFFFFFu) {
+                a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
+                idx = 0xFFFFFFFFu;
+            }
+            if (!exhausted) {
+                if (pool_next == pool_end) {
+                    const int leader = __ffsll((long long)mask) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(work, a.chunk);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                    pool_next = base < total ? base : total;
+                    pool_end = (base + a.chunk) < total ? (base + a.chunk) : total;
+                    if (base >= total) { pool_end = pool_next; exhausted = true; }
+                }
+                if (!exhausted) {
+                    if (need) {
+                        const uint32_t mine = pool_next + (uint32_t)__popcll(mask & lt_mask);
+                        if (mine < pool_end) {
+                            idx = a.wl ? a.wl[mine] : seg_nth(a.segs, mine);
+                            const double tmin = a.tmin ? a.tmin[idx] : 0.001, tmax = a.tmax ? a.tmax[idx] : RT_INF;
+                            const Ray w = ray_world(mk(a.q.ox[idx], a.q.oy[idx], a.q.oz[idx]), mk(a.q.dx[idx], a.q.dy[idx], a.q.dz[idx]));
+                            wide_begin(ln, S, W, w, tmin, tmax, trav_best_setup(a, idx));
+                        }
+                    }
+                    const uint32_t want = pool_next + (uint32_t)__popcll(mask);
+                    pool_next = want < pool_end ? want : pool_end;
+                }
+            }
+            if (exhausted && __ballot(ln.state != RT_W_DONE) == 0ull) break;
+            n_node = __popcll(__ballot(ln.state == RT_W_NODE));
+            n_prim = __popcll(__ballot(ln.state == RT_W_PRIM));
+        }
+        const bool do_node = n_node >= RT_WIDE_STEP_THRESHOLD || n_node >= n_prim;
+        const bool do_prim = n_prim >= RT_WIDE_STEP_THRESHOLD || n_prim > n_node;
+        if (do_node && ln.state == RT_W_NODE) wide_node_step(W, ln);
+        if (do_prim && ln.state == RT_W_PRIM) wide_prim_step<false>(S, W, ln, tally);
+    }
 }
 
 // Whole paths for trees WITHOUT BVH entries, where every ray does the same work: get_ray, then ray_color as a
@@ -429,7 +536,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
                                                        Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
-                                                       uint32_t iter, uint32_t max_depth) {
+                                                       uint32_t iter, uint32_t max_depth, Gates gates, HitBuf hb_out) {
     __shared__ uint32_t wave_total[SHADE_BLOCK / 64][4];
     __shared__ uint32_t block_base[4];
     uint32_t n;
@@ -499,15 +606,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         block_base[threadIdx.x] = tot ? atomicAdd(out_count + RT_COUNT_STRIDE * threadIdx.x, tot) : 0u;
     }
     __syncthreads();
+    uint32_t dst = 0u;
     if (alive) {
-        uint32_t dst = cls * segs.stride + block_base[cls] + wave_total[wave][cls] + prefix;
+        dst = cls * segs.stride + block_base[cls] + wave_total[wave][cls] + prefix;
         out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
         out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
         out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
         out.ctr[dst] = ctr;
         out.sig[dst] = sig;
+        if (gates.n) { hb_out.t[dst] = RT_INF; hb_out.ref[dst] = RT_NO_HIT; }
     }
+    gates_append(gates, alive, dst, no, nd, out_count);
 }
 
 // One whole bounce for trees WITHOUT BVH entries: the lockstep walk of k_traverse_lockstep followed, in the same
@@ -784,12 +894,16 @@ struct rt_scene {
     // A tree with BVH entries is walked in stretches of whole top-level entries: those without a BVH entry below them
     // (every ray does the same work there) by the lockstep kernel, the others by the persistent one; the closest hit
     // so far travels from one launch to the next in the hit buffer.
-    struct Stretch { uint32_t first, end; bool lockstep; };
     std::vector<Stretch> stretches;
+    std::vector<WideBvh> wide;     // the four-wide trees of the BVH entries that take one (rt_wide.h)
+    std::vector<DWide> d_wide;     // on the device
+    GateInfo gate;                 // one gate per wide tree (the first RT_MAX_GATES of them): wide tree w has gate w
+    const GateInfo* d_gate = nullptr;
     int media_mode = RT_MEDIA_NONE;  // RT_MEDIA_FLAT when every medium's boundary is plain primitives, else RT_MEDIA_ANY
     bool plain = false;   // only Lambertian / DiffuseLight / Isotropic over SolidColor: selects the lean shade kernel
     uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
     uint32_t path_waves = 0;     // the same for the whole-path kernel
+    uint32_t wide_waves = 0;     // the same for the wide-tree kernel
     std::vector<void*> allocs;
     DScene d;
     const uint4* nodes_nocull = nullptr;  // the tree with every cull box infinite (RT_FLAG_NO_CULL)
@@ -804,7 +918,9 @@ struct rt_scene {
     size_t ws_paths = 0, ws_lum = 0, ws_hits = 0;
     std::vector<void*> ws_allocs;
     Queue qa, qb;
-    HitBuf hb;
+    HitBuf hb, hb2;   // closest hits of the rays in qa / qb (hb2 only where work lists are in use)
+    uint32_t* wl = nullptr;  // work lists, ws_paths slots each
+    size_t ws_lists = 0;
     double *lum_r = nullptr, *lum_g = nullptr, *lum_b = nullptr;
     uint32_t* d_count = nullptr;
     unsigned long long* d_tallies = nullptr;
@@ -1042,18 +1158,13 @@ static int validate(rt_scene* s) {
         s->plain = s->plain && kind_ok && s->texs[m.texture].kind == RT_TEX_SOLID;
     }
     if (s->levels > RT_MAX_LEVELS) return fail(RT_ERR_LIMIT, "scene needs %u levels, limit %d", s->levels, RT_MAX_LEVELS);
-    s->stretches.clear();
-    for (uint32_t i = 0; i < nn;) {
-        const rt_node& n = s->nodes[i];
-        const uint32_t next = (n.kind == RT_NODE_BVH || n.kind == RT_NODE_MEDIUM || n.kind == RT_NODE_CULL) ? n.skip : i + 1u;
-        bool uniform = true;
-        for (uint32_t j = i; j < next; ++j) uniform = uniform && s->nodes[j].kind != RT_NODE_BVH;
-        if (!s->has_bvh) uniform = true;
-        if (!s->stretches.empty() && s->stretches.back().lockstep == uniform) s->stretches.back().end = next;
-        else s->stretches.push_back({i, next, uniform});
-        i = next;
-    }
-    if (s->stretches.empty()) s->stretches.push_back({0u, 0u, true});
+    s->wide.clear();
+    s->stretches = build_stretches(s->nodes.data(), nn, s->has_bvh, [&](uint32_t e) -> int {
+        WideBvh w;
+        if (!build_wide(s->nodes.data(), nn, e, s->boxes.data(), s->spheres.data(), s->quads.data(), s->tris.data(), w)) return -1;
+        s->wide.push_back(std::move(w));
+        return (int)s->wide.size() - 1;
+    });
     return RT_OK;
 }
 
@@ -1119,6 +1230,31 @@ int rt_scene_commit(rt_scene* s, int device) {
         d.nodes = reinterpret_cast<const uint4*>(d_rec);
         s->nodes_nocull = reinterpret_cast<const uint4*>(d_rec_nc);
     }
+    s->d_wide.clear();
+    for (const WideBvh& w : s->wide) {
+        DWide dw;
+        const uint32_t* dn = nullptr;
+        const double* db = nullptr;
+        if ((rc = upload(s, w.nodes, &dn))) return rc;
+        if ((rc = upload(s, w.refbox, &db))) return rc;
+        dw.nodes = reinterpret_cast<const uint4*>(dn);
+        dw.refbox = reinterpret_cast<const double2*>(db);
+        dw.K = w.K; dw.lambda = w.lambda; dw.chain = w.chain;
+        s->d_wide.push_back(dw);
+    }
+    {
+        DScene h;  // host pointers, for chain_map
+        std::memset(&h, 0, sizeof h);
+        h.chains = s->chains.data(); h.ops = s->ops.data();
+        std::memset(&s->gate, 0, sizeof s->gate);
+        s->gate.n = (uint32_t)std::min<size_t>(s->wide.size(), RT_MAX_GATES);
+        for (uint32_t b = 0; b < s->gate.n; ++b) {
+            std::memcpy(s->gate.box[b], s->wide[b].bounds, 48);
+            chain_map(h, s->wide[b].chain, s->gate.xf[b]);
+        }
+        const std::vector<GateInfo> one(1, s->gate);
+        if ((rc = upload(s, one, &s->d_gate))) return rc;
+    }
     {
         std::vector<uint32_t> axis = quad_axis_flags(s->quads.data(), s->quad_mat.size());
         UP(axis, quad_axis);
@@ -1178,6 +1314,9 @@ int rt_scene_commit(rt_scene* s, int device) {
         }
         if (per_cu < 1) per_cu = 1;
         s->path_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_wide, TRAV_BLOCK, 0));
+        if (per_cu < 1) per_cu = 1;
+        s->wide_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }
     s->committed = true;
     return RT_OK;
@@ -1222,10 +1361,20 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
     // every stretch of the queue starts a workgroup of its own
     const uint32_t waves = (n_upper + TRAV_BLOCK - 1) / TRAV_BLOCK + (a_.segs.in_count ? a_.segs.nclass + 1u : 0u);
     for (size_t k = 0; k < s->stretches.size(); ++k) {
-        const rt_scene::Stretch& st = s->stretches[k];
+        const Stretch& st = s->stretches[k];
         TravArgs a = a_;
-        a.first = st.first; a.end = st.end; a.resume = k > 0 ? 1u : 0u;
-        if (st.lockstep) {
+        a.first = st.first; a.end = st.end; a.resume = (k > 0 || a_.resume) ? 1u : 0u;
+        a.wl = nullptr; a.wl_count = nullptr;
+        if (st.kind == RT_STRETCH_WIDE && !count && !nocull) {
+            if (a_.wl && (uint32_t)st.wide < s->gate.n) {  // a_.wl / a_.wl_count: the lists' base and the counter set
+                a.wl = a_.wl + (size_t)st.wide * s->ws_paths;
+                a.wl_count = a_.wl_count + RT_COUNT_STRIDE * (4u + (uint32_t)st.wide);
+            }
+            HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
+            const uint32_t grid = std::min(waves, s->wide_waves);
+            a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
+            hipLaunchKernelGGL(k_traverse_wide, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4);
+        } else if (st.kind == RT_STRETCH_LOCKSTEP) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
             if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
             else if (s->media_mode == RT_MEDIA_NONE) LOCKSTEP(false, RT_MEDIA_NONE);
@@ -1331,14 +1480,15 @@ static int ws_queue(rt_scene* s, Queue& q, size_t n) {
     }
     return RT_OK;
 }
-static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits) {
-    if (s->ws_paths >= paths && s->ws_lum >= lum && s->ws_hits >= hits) return RT_OK;
+static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits, size_t lists = 0) {
+    if (s->ws_paths >= paths && s->ws_lum >= lum && s->ws_hits >= hits && s->ws_lists >= lists) return RT_OK;
     free_list(s->ws_allocs);
     int rc;
     paths = std::max(paths, s->ws_paths);  // what is freed above is allocated again, never less
     lum = std::max(lum, s->ws_lum);
     hits = std::max(hits, s->ws_hits);
-    s->ws_paths = s->ws_lum = s->ws_hits = 0;
+    lists = std::max(lists, s->ws_lists);
+    s->ws_paths = s->ws_lum = s->ws_hits = s->ws_lists = 0;
     if (paths) {
         if ((rc = ws_queue(s, s->qa, paths))) return rc;
         if ((rc = ws_queue(s, s->qb, paths))) return rc;
@@ -1348,12 +1498,19 @@ static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits) 
         HIP_TRY(hipMalloc((void**)&s->hb.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
         HIP_TRY(hipMalloc((void**)&s->hb.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
     }
+    if (lists) {  // work lists are in use: a hit buffer for the second queue too, and the lists (one queue's length each)
+        HIP_TRY(hipMalloc((void**)&s->hb2.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb2.t);
+        HIP_TRY(hipMalloc((void**)&s->hb2.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.ref);
+        HIP_TRY(hipMalloc((void**)&s->hb2.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.chain);
+        HIP_TRY(hipMalloc((void**)&s->wl, lists * paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->wl);
+    }
     HIP_TRY(hipMalloc((void**)&s->lum_r, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
     HIP_TRY(hipMalloc((void**)&s->lum_g, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
     HIP_TRY(hipMalloc((void**)&s->lum_b, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
     s->ws_paths = paths;
     s->ws_lum = lum;
     s->ws_hits = hits;
+    s->ws_lists = lists;
     return RT_OK;
 }
 
@@ -1464,8 +1621,15 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         const uint32_t nclass = lockstep ? 1u << s->sig.n : 1u;
         const uint64_t rows = (uint64_t)nclass * qcap + bsize;
         if (rows > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
-        if ((rc = ensure_workspace(s, (size_t)rows, (size_t)(bsize * nslots), bounce ? 0 : (size_t)rows))) return rc;
         const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
+        // work lists for the launches that walk wide trees: only where more than one launch makes up a bounce (a
+        // lone tree's bounds are the scene's: every ray reaches them)
+        const bool gated = !lockstep && !count && !nocull && s->gate.n > 0 && s->stretches.size() > 1;
+        if ((rc = ensure_workspace(s, (size_t)rows, (size_t)(bsize * nslots), bounce ? 0 : (size_t)rows, gated ? s->gate.n : 0))) return rc;
+        Gates gates;
+        std::memset(&gates, 0, sizeof gates);
+        if (gated) { gates.info = s->d_gate; gates.lists = s->wl; gates.stride = (uint32_t)s->ws_paths; gates.n = s->gate.n; }
+        HitBuf hb_in = s->hb, hb_out = gated ? s->hb2 : s->hb;
         auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
         // How many rays each launch leaves behind is counted on the device, and the next launch reads it there.  The
         // host reads those counts RT_LAG iterations late: until then it works with upper bounds (a ray count only
@@ -1523,7 +1687,8 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                 const uint32_t ns = batch_samples(injected), nb = ns * npix;
                 const uint32_t slot0 = (uint32_t)((injected % nslots) * bsize);
                 hipLaunchKernelGGL(k_raygen, dim3((nb + 255u) / 256u), dim3(256), 0, sm, s->d_sig, *cam, o->seed, npix,
-                                   o->spp_begin + injected * spb, nb, nclass * (uint32_t)qcap, slot0, iter, qin);
+                                   o->spp_begin + injected * spb, nb, nclass * (uint32_t)qcap, slot0, iter, qin, gates, hb_in,
+                                   s->d_ring + (iter % RT_RING) * RT_RING_WORDS);
                 born_at[injected] = iter;
                 injected++;
                 fresh = nb;
@@ -1590,12 +1755,13 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             } else {
                 TravArgs ta;
                 std::memset(&ta, 0, sizeof ta);
-                ta.q = qin; ta.hb = s->hb; ta.seed = o->seed; ta.segs = segs;
+                ta.q = qin; ta.hb = hb_in; ta.seed = o->seed; ta.segs = segs;
+                if (gated) { ta.resume = 1u; ta.wl = s->wl; ta.wl_count = segs.in_count; }
                 if ((rc = launch_traverse(s, ta, count, nocull, upper_in))) return rc;
                 HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
                 const uint32_t sblocks = (upper_in + SHADE_BLOCK - 1) / SHADE_BLOCK + nclass + 1u;
-#define SHADE_ARGS s->d, s->d_sig, o->seed, segs, qin, s->hb, qout, out_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
-                   o->background[1], o->background[2], iter, o->max_depth
+#define SHADE_ARGS s->d, s->d_sig, o->seed, segs, qin, hb_in, qout, out_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
+                   o->background[1], o->background[2], iter, o->max_depth, gates, hb_out
                 if (s->plain) hipLaunchKernelGGL(k_shade<true>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
                 else hipLaunchKernelGGL(k_shade<false>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
 #undef SHADE_ARGS
@@ -1605,6 +1771,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
             HIP_TRY(hipEventRecord(s->ring_ev[r][3], sm));
             HIP_TRY(hipGetLastError());
             std::swap(qin, qout);
+            std::swap(hb_in, hb_out);
         }
         while (consumed < hist.size()) if ((rc = consume())) return rc;
         if (finished) {

@@ -613,44 +613,73 @@ RT_HD bool line_off_axis(double mi, double mj, double di, double dj, double hi, 
     const double a = mi * dj, b = mj * di;
     return fabs(a - b) > (hi * fabs(dj) + hj * fabs(di)) * (1.0 + 1e-9) + 1e-9 * (fabs(a) + fabs(b));
 }
+// Whether the line through (o, d) -- with `half`, its part t >= 0 -- cannot touch `box6` (x, y, z: start, end) once
+// taken through the affine map A (12 values: a row-major 3 x 3 matrix, then the translation).
+RT_HD bool line_misses_box(const double* A, const double* box6, V3 o, V3 d, bool half) {
+    const V3 co = mk(A[0] * o.x + A[1] * o.y + A[2] * o.z + A[9], A[3] * o.x + A[4] * o.y + A[5] * o.z + A[10],
+                     A[6] * o.x + A[7] * o.y + A[8] * o.z + A[11]);
+    const V3 cd = mk(A[0] * d.x + A[1] * d.y + A[2] * d.z, A[3] * d.x + A[4] * d.y + A[5] * d.z,
+                     A[6] * d.x + A[7] * d.y + A[8] * d.z);
+    // line against box without a division: a line misses a box exactly when one of the axes d x e_k separates
+    // them (or, with d_k = 0, the box's own axis e_k does)
+    const V3 h = mk(0.5 * (box6[1] - box6[0]), 0.5 * (box6[3] - box6[2]), 0.5 * (box6[5] - box6[4]));
+    const V3 m = mk(co.x - 0.5 * (box6[0] + box6[1]), co.y - 0.5 * (box6[2] + box6[3]), co.z - 0.5 * (box6[4] + box6[5]));
+    bool off = line_off_axis(m.y, m.z, cd.y, cd.z, h.y, h.z) || line_off_axis(m.z, m.x, cd.z, cd.x, h.z, h.x) ||
+               line_off_axis(m.x, m.y, cd.x, cd.y, h.x, h.y) || (cd.x == 0.0 && fabs(m.x) > h.x * (1.0 + 1e-9)) ||
+               (cd.y == 0.0 && fabs(m.y) > h.y * (1.0 + 1e-9)) || (cd.z == 0.0 && fabs(m.z) > h.z * (1.0 + 1e-9));
+    if (half) {
+        // the whole box behind the origin: (p - o) . d < 0 for every point p of the box (the largest value is taken
+        // corner by corner), with slack far above the rounding of the products
+        const double ax = (box6[0] - co.x) * cd.x, bx = (box6[1] - co.x) * cd.x;
+        const double ay = (box6[2] - co.y) * cd.y, by = (box6[3] - co.y) * cd.y;
+        const double az = (box6[4] - co.z) * cd.z, bz = (box6[5] - co.z) * cd.z;
+        const double top = fmax(ax, bx) + fmax(ay, by) + fmax(az, bz);
+        const double mag = fabs(ax) + fabs(bx) + fabs(ay) + fabs(by) + fabs(az) + fabs(bz);
+        off = off || top < -1e-9 * mag;
+    }
+    // anything out of the ordinary (infinite box, NaN) compares false above: "may touch"
+    return off;
+}
 RT_HD uint32_t ray_signature(const SigInfo& G, V3 o, V3 d) {
     uint32_t sig = 0xFFFFFFFFu;
-    const Ray w = ray_world(o, d);
 #pragma unroll
     for (uint32_t b = 0; b < RT_MAX_SIG; ++b) {
         if (b >= G.n) break;
-        const double* A = G.xf[b];
-        Ray c;
-        c.o = mk(A[0] * w.o.x + A[1] * w.o.y + A[2] * w.o.z + A[9], A[3] * w.o.x + A[4] * w.o.y + A[5] * w.o.z + A[10],
-                 A[6] * w.o.x + A[7] * w.o.y + A[8] * w.o.z + A[11]);
-        c.d = mk(A[0] * w.d.x + A[1] * w.d.y + A[2] * w.d.z, A[3] * w.d.x + A[4] * w.d.y + A[5] * w.d.z,
-                 A[6] * w.d.x + A[7] * w.d.y + A[8] * w.d.z);
-        double2 bx, by, bz;
-        bx.x = G.box[b][0]; bx.y = G.box[b][1]; by.x = G.box[b][2]; by.y = G.box[b][3];
-        bz.x = G.box[b][4]; bz.y = G.box[b][5];
-        // line against box without a division: a line misses a box exactly when one of the axes d x e_k separates
-        // them (or, with d_k = 0, the box's own axis e_k does)
-        const V3 h = mk(0.5 * (bx.y - bx.x), 0.5 * (by.y - by.x), 0.5 * (bz.y - bz.x));
-        const V3 m = mk(c.o.x - 0.5 * (bx.x + bx.y), c.o.y - 0.5 * (by.x + by.y), c.o.z - 0.5 * (bz.x + bz.y));
-        const bool off = line_off_axis(m.y, m.z, c.d.y, c.d.z, h.y, h.z) || line_off_axis(m.z, m.x, c.d.z, c.d.x, h.z, h.x) ||
-                         line_off_axis(m.x, m.y, c.d.x, c.d.y, h.x, h.y) || (c.d.x == 0.0 && fabs(m.x) > h.x * (1.0 + 1e-9)) ||
-                         (c.d.y == 0.0 && fabs(m.y) > h.y * (1.0 + 1e-9)) || (c.d.z == 0.0 && fabs(m.z) > h.z * (1.0 + 1e-9));
-        // anything out of the ordinary (infinite box, NaN) compares false above and keeps the bit
-        if (off) sig &= ~(1u << b);
+        if (line_misses_box(G.xf[b], G.box[b], o, d, false)) sig &= ~(1u << b);
     }
     return sig;
 }
+// Gates (trees with BVH entries; no counterpart in the reference, results unchanged): entry b describes the bounds of
+// everything below one top-level BVH entry, in that entry's instance chain.  Bit b of a ray's gate mask is clear
+// when the ray -- t >= 0, which every ray of a render satisfies (camera.rs:363 starts at 0.001) -- cannot reach them;
+// the launch that walks that entry is then handed only the rays whose bit is set.
+#define RT_MAX_GATES 12u
+struct GateInfo {
+    uint32_t n, reserved;
+    double box[RT_MAX_GATES][6];
+    double xf[RT_MAX_GATES][12];
+};
+RT_HD uint32_t ray_gates(const GateInfo& G, V3 o, V3 d) {
+    uint32_t bits = 0u;
+    for (uint32_t b = 0; b < G.n; ++b)
+        if (!line_misses_box(G.xf[b], G.box[b], o, d, true)) bits |= 1u << b;
+    return bits;
+}
 // Host side: entry b of the signature from tree entry `n` (a CULL entry), its box, and the scene's chains / ops.
-inline void signature_entry(SigInfo& G, const DScene& S, uint32_t b, const rt_node& n, const double* box6) {
-    for (int k = 0; k < 6; ++k) G.box[b][k] = box6[k];
+// (S needs its chains and ops only, as host pointers.)
+inline void chain_map(const DScene& S, uint32_t chain, double* xf12) {
     const V3 e[4] = {mk(0, 0, 0), mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
     V3 img[4];
-    for (int k = 0; k < 4; ++k) img[k] = ray_in_chain(S, ray_world(e[k], mk(0, 0, 1)), n.chain).o;
+    for (int k = 0; k < 4; ++k) img[k] = ray_in_chain(S, ray_world(e[k], mk(0, 0, 1)), chain).o;
     for (int k = 0; k < 3; ++k) {
         const V3 col = img[k + 1] - img[0];
-        G.xf[b][0 + k] = col.x; G.xf[b][3 + k] = col.y; G.xf[b][6 + k] = col.z;
+        xf12[0 + k] = col.x; xf12[3 + k] = col.y; xf12[6 + k] = col.z;
     }
-    G.xf[b][9] = img[0].x; G.xf[b][10] = img[0].y; G.xf[b][11] = img[0].z;
+    xf12[9] = img[0].x; xf12[10] = img[0].y; xf12[11] = img[0].z;
+}
+inline void signature_entry(SigInfo& G, const DScene& S, uint32_t b, const rt_node& n, const double* box6) {
+    for (int k = 0; k < 6; ++k) G.box[b][k] = box6[k];
+    chain_map(S, n.chain, G.xf[b]);
 }
 // What a wavefront of the lockstep walk may pass over: bit b set when no lane's signature has bit b (`sig` of a lane
 // without a ray: 0).  The same value in every lane.
@@ -1122,13 +1151,15 @@ RT_HD void lane_medium_step(const DScene& S, const Src& src, Lane& ln, const Lev
 // The next primitive(s) of the run in progress for a lane in RT_ST_RUN: two per step where the run has two left, so
 // that both records are in flight together and the step's fixed costs are shared.
 // Moves a lane whose run has a pair mask (bit 0 of `mask` = the pair at ln.k) on to the next pair worth testing.
-RT_HD void lane_skip_pairs(Lane& ln, uint32_t mask) {
+template <class LaneT>
+RT_HD void lane_skip_pairs(LaneT& ln, uint32_t mask) {
     mask &= 0xFFu;
     while (ln.k < ln.kend && (mask & 1u) == 0u) { ln.k += 2u; mask >>= 1; }
     ln.kind = (ln.kind & 0xFFFFu) | mask << 16;
 }
-template <bool COUNT>
-RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
+// (The tests themselves, for any lane type with the run fields of Lane; the caller moves the lane on once k >= kend.)
+template <bool COUNT, class LaneT>
+RT_HD void lane_prim_tests(const DScene& S, LaneT& ln, Tally& tally) {
     const bool two = ln.k + 1u < ln.kend;
     double t;
     const uint32_t kind = ln.kind & 0xFFu;
@@ -1162,7 +1193,6 @@ RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
             }
         }
         ln.k = ln.k + done;
-        if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
         return;
     } else {
         if (COUNT) { tally.prim_tests++; tally.prim_bytes += 88u; tally.prim_flops += 70u; }
@@ -1171,11 +1201,14 @@ RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
             ln.e = t;
         }
         ln.k = ln.k + 1u;
-        if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
         return;
     }
     ln.k = ln.k + (two ? 2u : 1u);
     if (ln.kind & 0x100u) lane_skip_pairs(ln, (ln.kind >> 16) >> 1);
+}
+template <bool COUNT>
+RT_HD void lane_prim_step(const DScene& S, Lane& ln, Tally& tally) {
+    lane_prim_tests<COUNT>(S, ln, tally);
     if (ln.k >= ln.kend) { ln.state = RT_ST_NODE; ln.i = ln.i + 1u; }
 }
 // A leaf's run with cull boxes per pair of primitives (no counterpart in the reference; results unchanged: a pair is

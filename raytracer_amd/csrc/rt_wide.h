@@ -1,0 +1,355 @@
+// rt_wide.h -- a four-wide acceleration tree over the LEAVES of a reference BVH, and the per-lane walk that uses it.
+//
+// Why the reference's inner nodes can be replaced.  BVHNode::hit (bvh.rs:29-60) narrows the ray interval by its box
+// and hands the result to its children.  Every box is the union of the boxes of the objects below it (bvh.rs:88-92),
+// so a child's box lies inside its parent's, and so does the slab interval a ray cuts out of it, bound by bound
+// ((lo - o) * inv is monotone in lo).  Narrowing by parent and child therefore gives what narrowing by the child
+// alone gives, and a parent that misses implies a child that misses: what a leaf's primitives are tested against is
+// (tmin, min(tmax, closest so far)) narrowed by the LEAF's box alone, and a leaf is entered exactly when that test
+// passes.  The inner nodes decide nothing but which leaves are looked at -- in the reference's order, upper half
+// first (bvh.rs:50-57,127-130).  build_wide checks the nesting box by box (and that no box is degenerate) and refuses
+// the tree otherwise; such a tree keeps the entry-by-entry walk of rt_core.h.
+//
+// The tree built here: the leaves in visiting order, each cut into items (a pair of triangles or quads with the box
+// around their corners, a whole run of spheres, one box-shaped list of quads, ...), every leaf padded to 4^lambda
+// item slots.  Above the items sits a complete 4-ary tree in heap order: node (k, g) covers slots
+// [g * 4^k, (g + 1) * 4^k) and holds the boxes of its four children as f32, rounded outwards (none of them narrows
+// anything: a subtree is passed over only when the ray's interval cannot touch the geometry below it).  A lane walks
+// it with a cursor that only moves forward, as the reference does, and remembers which children of the nodes above
+// it are still to be visited in four bits per level of one 64-bit register.  The level-lambda node of a leaf is where
+// the leaf's own f64 box does the reference's narrowing (for lambda = 0 the first primitive step does it).
+#pragma once
+
+#include "rt_core.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace rt {
+
+struct DWide {               // as the kernels see it
+    const uint4* nodes;      // 128 bytes per node: 4 x 6 f32 child boxes (x, y, z: start, end) | level-1 nodes only: the
+                             // four items as (first primitive, kind << 24 | count)
+    const double2* refbox;   // per leaf: the reference's box, 3 x (start, end)
+    uint32_t K;              // the root is node (K, 0)
+    uint32_t lambda;         // a leaf covers 4^lambda item slots
+    uint32_t chain;          // the instance chain the whole tree lives in
+};
+RT_HD uint32_t wide_node_index(uint32_t K, uint32_t k, uint32_t g) {
+    return (0x55555555u & ((1u << (2u * (K - k))) - 1u)) + g;  // (4^(K-k) - 1) / 3 nodes lie above level k
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+struct WideBvh {
+    uint32_t entry = 0, end = 0, chain = 0, K = 0, lambda = 0, leaves = 0;
+    std::vector<uint32_t> nodes;  // 32 words per node
+    std::vector<double> refbox;   // 6 per leaf
+    double bounds[6] = {0, 0, 0, 0, 0, 0};  // of everything below the entry (x, y, z: start, end), in its chain
+};
+namespace wide_detail {
+struct Item { uint32_t kind, first, count; double box[6]; };
+struct Leaf { uint32_t box; std::vector<Item> items; };
+struct Ctx {
+    const rt_node* nodes; size_t n; const double* boxes; const double* spheres; const double* quads; const double* tris;
+    uint32_t chain; std::vector<Leaf> leaves;
+};
+inline void grow(double* box, double lo, double hi, int c) {
+    const double inf = std::numeric_limits<double>::infinity();
+    if (!(lo == lo) || !(hi == hi)) { box[2 * c] = -inf; box[2 * c + 1] = inf; return; }  // NaN: no culling
+    const double a = std::isfinite(lo) ? lo - 1e-5 * (1.0 + std::fabs(lo)) : lo;
+    const double b = std::isfinite(hi) ? hi + 1e-5 * (1.0 + std::fabs(hi)) : hi;
+    box[2 * c] = std::min(box[2 * c], a);
+    box[2 * c + 1] = std::max(box[2 * c + 1], b);
+}
+// Bounds of every point primitives [first, first + count) of one kind can report a hit at, widened by
+// 1e-5 (1 + |coordinate|) like the cull boxes of the host layer.
+inline void prim_box(const Ctx& c, uint32_t kind, uint32_t first, uint32_t count, double* box) {
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int a = 0; a < 3; ++a) { box[2 * a] = inf; box[2 * a + 1] = -inf; }
+    for (uint32_t k = first; k < first + count; ++k) {
+        for (int a = 0; a < 3; ++a) {
+            if (kind == RT_NODE_SPHERES) {
+                const double* s = c.spheres + 4 * (size_t)k;
+                grow(box, s[a] - std::fabs(s[3]), s[a] + std::fabs(s[3]), a);
+            } else if (kind == RT_NODE_QUADS || kind == RT_NODE_TRIANGLES) {
+                const double* r = (kind == RT_NODE_QUADS ? c.quads : c.tris) + 16 * (size_t)k;  // n d q u v w
+                const double q = r[4 + a], u = r[7 + a], v = r[10 + a];
+                const double corner[4] = {q, q + u, q + v, kind == RT_NODE_QUADS ? q + u + v : q};
+                for (double x : corner) grow(box, x, x, a);
+            } else {
+                grow(box, -inf, inf, a);  // a quadric is unbounded
+            }
+        }
+    }
+}
+inline bool is_run(uint8_t kind) { return kind >= RT_NODE_SPHERES && kind <= RT_NODE_QUADRICS; }
+inline bool collect(Ctx& c, uint32_t e, int parent, int depth) {
+    if (depth > 40) return false;
+    const rt_node& n = c.nodes[e];
+    if (n.kind != RT_NODE_BVH || n.chain != c.chain || n.skip <= e || n.skip > c.n) return false;
+    const double* b = c.boxes + 6 * (size_t)n.first;
+    for (int a = 0; a < 3; ++a) {
+        if (!(b[2 * a] < b[2 * a + 1])) return false;  // degenerate (or NaN): the nesting argument needs lo < hi
+        if (parent >= 0) {
+            const double* pb = c.boxes + 6 * (size_t)c.nodes[parent].first;
+            if (!(b[2 * a] >= pb[2 * a] && b[2 * a + 1] <= pb[2 * a + 1])) return false;
+        }
+    }
+    if (e + 1 < n.skip && c.nodes[e + 1].kind == RT_NODE_BVH) {
+        for (uint32_t ch = e + 1; ch < n.skip; ch = c.nodes[ch].skip) {
+            if (c.nodes[ch].kind != RT_NODE_BVH || c.nodes[ch].level != n.level + 1u) return false;
+            if (!collect(c, ch, (int)e, depth + 1)) return false;
+        }
+        return true;
+    }
+    Leaf leaf;
+    leaf.box = n.first;
+    for (uint32_t j = e + 1; j < n.skip;) {
+        const rt_node& x = c.nodes[j];
+        if (x.chain != c.chain || x.level != n.level + 1u) return false;
+        const rt_node* run = nullptr;
+        bool bare = false;
+        if (is_run(x.kind)) { run = &x; bare = true; j = j + 1; }
+        else if (x.kind == RT_NODE_CULL && x.skip == j + 2 && x.skip <= n.skip && is_run(c.nodes[j + 1].kind) &&
+                 c.nodes[j + 1].chain == c.chain && c.nodes[j + 1].level == n.level + 1u) { run = &c.nodes[j + 1]; j = x.skip; }
+        else return false;
+        if (run->count == 0 || run->count >= (1u << 24)) { if (run->count == 0) continue; return false; }
+        const bool planar = run->kind == RT_NODE_QUADS || run->kind == RT_NODE_TRIANGLES;
+        if (bare && planar && run->count >= 3) {  // pairs, each with the box around its corners
+            for (uint32_t k = 0; k < run->count; k += 2) {
+                Item it; it.kind = run->kind; it.first = run->first + k; it.count = std::min(2u, run->count - k);
+                prim_box(c, it.kind, it.first, it.count, it.box);
+                leaf.items.push_back(it);
+            }
+        } else {
+            Item it; it.kind = run->kind; it.first = run->first; it.count = run->count;
+            prim_box(c, it.kind, it.first, it.count, it.box);
+            leaf.items.push_back(it);
+        }
+    }
+    c.leaves.push_back(std::move(leaf));
+    return true;
+}
+inline void outward(const double* box6, float* out6) {
+    if (!(box6[0] <= box6[1])) {  // empty: (inf, inf) fails the slab test whatever the ray
+        for (int k = 0; k < 6; ++k) out6[k] = std::numeric_limits<float>::infinity();
+        return;
+    }
+    for (int k = 0; k < 6; ++k) {
+        float f = (float)box6[k];
+        if (!(k & 1) && (double)f > box6[k]) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+        if ((k & 1) && (double)f < box6[k]) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+        out6[k] = f;
+    }
+}
+}  // namespace wide_detail
+
+// Builds the wide tree for the top-level BVH entry `root` (level 0).  False when the subtree is not of the shape
+// described above; the caller then walks it entry by entry.
+inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, const double* boxes, const double* spheres,
+                       const double* quads, const double* tris, WideBvh& out) {
+    using namespace wide_detail;
+    if (root >= n_nodes || nodes[root].kind != RT_NODE_BVH || nodes[root].level != 0) return false;
+    Ctx c; c.nodes = nodes; c.n = n_nodes; c.boxes = boxes; c.spheres = spheres; c.quads = quads; c.tris = tris;
+    c.chain = nodes[root].chain;
+    if (!collect(c, root, -1, 0) || c.leaves.empty()) return false;
+    size_t most = 0;
+    for (const Leaf& l : c.leaves) most = std::max(most, l.items.size());
+    uint32_t lambda = 0;
+    while ((1ull << (2 * lambda)) < most) ++lambda;
+    if (lambda > 3) return false;
+    const uint64_t slots = (uint64_t)c.leaves.size() << (2 * lambda);
+    uint32_t K = std::max(1u, lambda);
+    while ((1ull << (2 * K)) < slots) ++K;
+    if (K > 12) return false;  // 16 M item slots; four pending bits per level fit one 64-bit register up to K = 15
+    out.entry = root; out.end = nodes[root].skip; out.chain = c.chain; out.K = K; out.lambda = lambda;
+    out.leaves = (uint32_t)c.leaves.size();
+    const double inf = std::numeric_limits<double>::infinity();
+    const size_t width = (size_t)1 << (2 * K);
+    std::vector<double> cur(6 * width);
+    for (size_t i = 0; i < width; ++i) for (int a = 0; a < 3; ++a) { cur[6 * i + 2 * a] = inf; cur[6 * i + 2 * a + 1] = -inf; }
+    std::vector<uint32_t> desc(2 * width, 0u);
+    out.refbox.resize(6 * c.leaves.size());
+    for (size_t l = 0; l < c.leaves.size(); ++l) {
+        std::memcpy(&out.refbox[6 * l], boxes + 6 * (size_t)c.leaves[l].box, 48);
+        for (size_t i = 0; i < c.leaves[l].items.size(); ++i) {
+            const Item& it = c.leaves[l].items[i];
+            const size_t slot = (l << (2 * lambda)) + i;
+            std::memcpy(&cur[6 * slot], it.box, 48);
+            desc[2 * slot] = it.first;
+            desc[2 * slot + 1] = it.kind << 24 | it.count;
+        }
+    }
+    const size_t total = (width - 1) / 3;
+    out.nodes.assign(32 * total, 0u);
+    size_t below = width;  // boxes in `cur` (level k - 1)
+    for (uint32_t k = 1; k <= K; ++k) {
+        const size_t count = below / 4;
+        std::vector<double> up(6 * count);
+        for (size_t g = 0; g < count; ++g) {
+            uint32_t* rec = &out.nodes[32 * (size_t)wide_node_index(K, k, (uint32_t)g)];
+            double u[6] = {inf, -inf, inf, -inf, inf, -inf};
+            for (int j = 0; j < 4; ++j) {
+                const double* b = &cur[6 * (4 * g + j)];
+                float f[6];
+                outward(b, f);
+                std::memcpy(rec + 6 * j, f, 24);
+                if (b[0] <= b[1]) for (int a = 0; a < 3; ++a) { u[2 * a] = std::min(u[2 * a], b[2 * a]); u[2 * a + 1] = std::max(u[2 * a + 1], b[2 * a + 1]); }
+                if (k == 1) { rec[24 + 2 * j] = desc[2 * (4 * g + j)]; rec[25 + 2 * j] = desc[2 * (4 * g + j) + 1]; }
+            }
+            std::memcpy(&up[6 * g], u, 48);
+        }
+        cur.swap(up);
+        below = count;
+    }
+    std::memcpy(out.bounds, cur.data(), 48);
+    return true;
+}
+
+// The stretches of top-level entries a tree with BVH entries is walked in, one launch each, the closest hit so far
+// travelling from one to the next: entries with no BVH entry below them (every ray does the same work there) together
+// by the lockstep walk; a BVH entry build_wide accepts (wide[k] >= 0 for top-level entry k... given per entry index)
+// by the wide walk, one stretch each; the rest by the entry-by-entry per-lane walk.
+#define RT_STRETCH_LOCKSTEP 0
+#define RT_STRETCH_LANES 1
+#define RT_STRETCH_WIDE 2
+struct Stretch { uint32_t first, end; int kind; int wide; };
+template <class Qualifies>  // int qualifies(uint32_t entry): index of the entry's wide tree, or -1
+inline std::vector<Stretch> build_stretches(const rt_node* nodes, uint32_t nn, bool has_bvh, Qualifies qualifies) {
+    std::vector<Stretch> out;
+    for (uint32_t i = 0; i < nn;) {
+        const rt_node& n = nodes[i];
+        const uint32_t next = (n.kind == RT_NODE_BVH || n.kind == RT_NODE_MEDIUM || n.kind == RT_NODE_CULL) ? n.skip : i + 1u;
+        bool uniform = true;
+        for (uint32_t j = i; j < next; ++j) uniform = uniform && nodes[j].kind != RT_NODE_BVH;
+        if (!has_bvh) uniform = true;
+        int kind = uniform ? RT_STRETCH_LOCKSTEP : RT_STRETCH_LANES, w = -1;
+        if (!uniform && n.kind == RT_NODE_BVH) { w = qualifies(i); if (w >= 0) kind = RT_STRETCH_WIDE; }
+        if (!out.empty() && out.back().kind == kind && kind != RT_STRETCH_WIDE) out.back().end = next;
+        else out.push_back({i, next, kind, w});
+        i = next;
+    }
+    if (out.empty()) out.push_back({0u, 0u, RT_STRETCH_LOCKSTEP, -1});
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------- the walk
+#define RT_W_NODE 0u
+#define RT_W_PRIM 1u
+#define RT_W_DONE 2u
+struct WLane {
+    Ray cur;                  // in the tree's chain, reciprocal direction ready
+    uint32_t cur_chain;
+    double tmin, tmax;        // the ray's interval at the top level
+    double s, e;              // inside a leaf: the interval its box narrowed that to, e shortened by every hit since
+    Best best;
+    unsigned long long pending;  // bits 4k .. 4k + 3: children of the level-k node above the cursor still to be visited
+    uint32_t slot, level;     // the node to look at next is (level, slot >> 2 level)
+    uint32_t k, kend, kind;   // run in progress; kind bit 9: the leaf's box has yet to narrow the interval (lambda = 0)
+    uint32_t d0x, d0y, d1x, d1y, d2x, d2y, d3x, d3y;  // the items of the level-1 node above the cursor
+    uint32_t state;
+};
+RT_HD void wide_begin(WLane& ln, const DScene& S, const DWide& W, const Ray& world, double tmin, double tmax, Best best) {
+    ln.cur = ray_in_chain(S, world, W.chain);
+    ray_need_inv(ln.cur);
+    ln.cur_chain = W.chain;
+    ln.tmin = tmin; ln.tmax = tmax; ln.s = tmin; ln.e = tmax;
+    ln.best = best;
+    ln.pending = 0ull;
+    ln.slot = 0u; ln.level = W.K;
+    ln.k = ln.kend = 0u; ln.kind = 0u;
+    ln.d0x = ln.d0y = ln.d1x = ln.d1y = ln.d2x = ln.d2y = ln.d3x = ln.d3y = 0u;
+    ln.state = RT_W_NODE;
+}
+RT_HD void wide_item_start(WLane& ln, const DWide& W, uint32_t j) {
+    // picked with masks, not with ?: on the fields (which the compiler turns into a load through a selected
+    // address, and the whole lane state then lives in scratch memory)
+    const uint32_t m0 = j == 0u ? 0xFFFFFFFFu : 0u, m1 = j == 1u ? 0xFFFFFFFFu : 0u, m2 = j == 2u ? 0xFFFFFFFFu : 0u,
+                   m3 = j == 3u ? 0xFFFFFFFFu : 0u;
+    const uint32_t first = (ln.d0x & m0) | (ln.d1x & m1) | (ln.d2x & m2) | (ln.d3x & m3);
+    const uint32_t kc = (ln.d0y & m0) | (ln.d1y & m1) | (ln.d2y & m2) | (ln.d3y & m3);
+    ln.kind = (kc >> 24) | (W.lambda == 0u ? 0x200u : 0u);
+    ln.k = first;
+    ln.kend = first + (kc & 0xFFFFFFu);
+    ln.state = RT_W_PRIM;
+}
+RT_HD uint32_t ctz64(unsigned long long x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(__ffsll((long long)x) - 1);
+#else
+    return (uint32_t)__builtin_ctzll(x);
+#endif
+}
+// On to the nearest child still to be visited of the nodes above the cursor, or done.
+RT_HD void wide_ascend(WLane& ln, const DWide& W) {
+    if (ln.pending == 0ull) { ln.state = RT_W_DONE; return; }
+    const uint32_t p = ctz64(ln.pending);
+    ln.pending &= ln.pending - 1ull;
+    const uint32_t k = p >> 2, j = p & 3u;
+    ln.slot = ((ln.slot >> (2u * k)) << (2u * k)) | (j << (2u * (k - 1u)));
+    if (k == 1u) { wide_item_start(ln, W, j); return; }
+    ln.level = k - 1u;
+    ln.state = RT_W_NODE;
+}
+RT_HD bool wide_box(const float4 a, const float2 b, const Ray& r, double s, double e) {
+    double2 x, y, z;
+    x.x = a.x; x.y = a.y; y.x = a.z; y.y = a.w; z.x = b.x; z.y = b.y;
+    return slab3(x, y, z, r, s, e);
+}
+// One node for a lane in RT_W_NODE: the reference's narrowing when the node is a leaf's, then its four child boxes.
+RT_HD void wide_node_step(const DWide& W, WLane& ln) {
+    const uint32_t k = ln.level;
+    const uint4* rp = W.nodes + 8u * wide_node_index(W.K, k, ln.slot >> (2u * k));
+    const float4* fp = reinterpret_cast<const float4*>(rp);
+    const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3], f4 = fp[4], f5 = fp[5];
+    if (k == 1u) {
+        const uint4 a = rp[6], b = rp[7];
+        ln.d0x = a.x; ln.d0y = a.y; ln.d1x = a.z; ln.d1y = a.w; ln.d2x = b.x; ln.d2y = b.y; ln.d3x = b.z; ln.d3y = b.w;
+    }
+    if (W.lambda != 0u && k == W.lambda) {  // BVHNode::hit's box test for the leaf (bvh.rs:31-37)
+        const double2* rb = W.refbox + 3u * (ln.slot >> (2u * W.lambda));
+        const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
+        double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
+        if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); return; }
+        ln.s = s; ln.e = e;
+    }
+    const bool inside = k <= W.lambda;
+    const double cs = inside ? ln.s : ln.tmin, ce = fmin(inside ? ln.e : ln.tmax, ln.best.t);
+    float2 t;
+    uint32_t m = 0u;
+    t.x = f1.x; t.y = f1.y; if (wide_box(f0, t, ln.cur, cs, ce)) m |= 1u;                                      // words 0..5
+    { float4 a; a.x = f1.z; a.y = f1.w; a.z = f2.x; a.w = f2.y; t.x = f2.z; t.y = f2.w; if (wide_box(a, t, ln.cur, cs, ce)) m |= 2u; }  // 6..11
+    t.x = f4.x; t.y = f4.y; if (wide_box(f3, t, ln.cur, cs, ce)) m |= 4u;                                      // 12..17
+    { float4 a; a.x = f4.z; a.y = f4.w; a.z = f5.x; a.w = f5.y; t.x = f5.z; t.y = f5.w; if (wide_box(a, t, ln.cur, cs, ce)) m |= 8u; }  // 18..23
+    if (m == 0u) { wide_ascend(ln, W); return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t j = (uint32_t)(__ffs((int)m) - 1);
+#else
+    const uint32_t j = (uint32_t)__builtin_ctz(m);
+#endif
+    m &= m - 1u;
+    ln.pending |= (unsigned long long)m << (4u * k);
+    ln.slot = ((ln.slot >> (2u * k)) << (2u * k)) | (j << (2u * (k - 1u)));
+    if (k == 1u) { wide_item_start(ln, W, j); return; }
+    ln.level = k - 1u;
+}
+// The next primitives of the run in progress for a lane in RT_W_PRIM (lane_prim_tests: two planar primitives or four
+// spheres per step).
+template <bool COUNT>
+RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tally) {
+    if (ln.kind & 0x200u) {  // lambda = 0: the item is a whole leaf, whose box narrows the interval first
+        ln.kind &= ~0x200u;
+        const double2* rb = W.refbox + 3u * ln.slot;
+        const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
+        double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
+        if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); return; }
+        ln.s = s; ln.e = e;
+    }
+    if (ln.k < ln.kend) lane_prim_tests<COUNT>(S, ln, tally);
+    if (ln.k >= ln.kend) wide_ascend(ln, W);
+}
+
+}  // namespace rt

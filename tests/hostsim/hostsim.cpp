@@ -7,6 +7,7 @@
 
 #include "../../raytracer_amd/csrc/rt_core.h"
 #include "../../raytracer_amd/csrc/rt_records.h"
+#include "../../raytracer_amd/csrc/rt_wide.h"
 
 using namespace rt;
 
@@ -58,7 +59,10 @@ static DScene to_dscene(const sim_scene* s) {
     return d;
 }
 
-static int mode = 0;  // 0 generic walk, 1 lockstep walk, 2 per-lane state machine
+static int mode = 0;  // 0 generic walk, 1 lockstep walk, 2 per-lane state machine, 3 stretches (lockstep / wide tree / state machine)
+static unsigned long long g_wide_stretches = 0, g_wide_steps = 0;
+extern "C" unsigned long long sim_wide_stretches(void) { return g_wide_stretches; }
+extern "C" unsigned long long sim_wide_steps(void) { return g_wide_steps; }
 extern "C" void sim_set_uniform_mode(int on) { host_uniform_mode() = on != 0; }
 extern "C" void sim_set_walk_mode(int m) { mode = m; }
 extern "C" void sim_set_cull(int on) { use_cull = on; }
@@ -74,6 +78,20 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
     double2 slots[RT_MAX_LEVELS];
     Levels L; L.base = slots; L.stride = 1;
     uint64_t nt = 0, pt = 0, ct = 0;
+    std::vector<WideBvh> wide;
+    std::vector<Stretch> stretches;
+    if (mode == 3) {
+        bool has_bvh = false;
+        for (uint64_t i = 0; i < sc->n_nodes; ++i) has_bvh |= sc->nodes[i].kind == RT_NODE_BVH;
+        stretches = build_stretches(sc->nodes, (uint32_t)sc->n_nodes, has_bvh, [&](uint32_t e) -> int {
+            WideBvh w;
+            if (!build_wide(sc->nodes, (size_t)sc->n_nodes, e, sc->boxes, sc->spheres, sc->quads, sc->tris, w)) return -1;
+            wide.push_back(std::move(w));
+            return (int)wide.size() - 1;
+        });
+        g_wide_stretches = wide.size();
+        g_wide_steps = 0;
+    }
     for (uint64_t i = 0; i < n; ++i) {
         Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
         RngPos rng;
@@ -84,7 +102,42 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
         uint32_t first = 0;  // a "wavefront" of one lane walks the tree without everything its signature rules out
         if (mode == 1 && use_sig) first = tree_without(S, sig_skip_mask(ray_signature(g_sig, w.o, w.d)));
         Best b;
-        if (mode == 2) {  // the per-lane state machine of the persistent kernel
+        if (mode == 3) {  // the launches of a tree with BVH entries, one after the other
+            b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
+            for (const Stretch& st : stretches) {
+                if (st.kind == RT_STRETCH_LOCKSTEP) {
+                    b = closest_hit_range<true, true>(S, src, tmin[i], tmax[i], L, rng, tally, st.first, st.end, b);
+                } else if (st.kind == RT_STRETCH_WIDE) {
+                    const WideBvh& wb = wide[(size_t)st.wide];
+                    DWide W;
+                    W.nodes = reinterpret_cast<const uint4*>(wb.nodes.data());
+                    W.refbox = reinterpret_cast<const double2*>(wb.refbox.data());
+                    W.K = wb.K; W.lambda = wb.lambda; W.chain = wb.chain;
+                    WLane wl;
+                    wide_begin(wl, S, W, w, tmin[i], tmax[i], b);
+                    while (wl.state != RT_W_DONE) {
+                        g_wide_steps++;
+                        if (wl.state == RT_W_NODE) wide_node_step(W, wl);
+                        else wide_prim_step<true>(S, W, wl, tally);
+                    }
+                    b = wl.best;
+                } else {
+                    DScene R = S;
+                    R.n_nodes = st.end;
+                    Lane ln;
+                    lane_begin(ln, src, tmin[i], tmax[i], L, st.first);
+                    ln.best = b;
+                    while (ln.state != RT_ST_DONE) {
+                        if (ln.state == RT_ST_NODE) lane_node_step<true>(R, src, ln, L, rng, tally);
+                        if (ln.state == RT_ST_RUN) lane_prim_step<true>(R, ln, tally);
+                        if (ln.state == RT_ST_MEDIUM) lane_medium_step<true>(R, src, ln, L, rng, tally);
+                        if (ln.state == RT_ST_CHAIN) lane_chain_step(R, src, ln);
+                        if (ln.state == RT_ST_SUB) lane_sub_step<true>(R, ln, tally);
+                    }
+                    b = ln.best;
+                }
+            }
+        } else if (mode == 2) {  // the per-lane state machine of the persistent kernel
             Lane ln;
             lane_begin(ln, src, tmin[i], tmax[i], L);
             while (ln.state != RT_ST_DONE) {

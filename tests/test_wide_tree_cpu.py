@@ -1,0 +1,137 @@
+"""The four-wide acceleration tree over the leaves of a reference BVH (raytracer_amd/csrc/rt_wide.h) and the walk in
+stretches of top-level entries, compiled for the host by tests/hostsim and compared with the oracle bit for bit:
+replacing the reference's inner nodes must change no hit, no primitive id and no random draw."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import SMALL, HostSim, assert_hits_equal, build_pair, cameras, path_rays
+
+BVH_CONFIGS = {"C1": 1, "C4": 2, "C5": 2}   # config -> top-level BVH entries that must take a wide tree
+
+
+@pytest.fixture(scope="module")
+def pairs():
+    cache = {}
+
+    def get(cfg):
+        if cfg not in cache:
+            hs, os_ = build_pair(cfg, **SMALL[cfg])
+            cache[cfg] = (hs, os_, HostSim(hs.builder))
+        return cache[cfg]
+
+    return get
+
+
+def _stretch_mode():
+    L = helpers._sim_lib()
+    L.sim_wide_stretches.restype = C.c_ulonglong
+    L.sim_wide_steps.restype = C.c_ulonglong
+    return L
+
+
+@pytest.mark.parametrize("cfg", sorted(BVH_CONFIGS))
+def test_stretches_with_wide_trees_match_oracle(pairs, cfg):
+    hs, os_, sim = pairs(cfg)
+    L = _stretch_mode()
+    _, oc = cameras(hs)
+    L.sim_set_walk_mode(3)
+    try:
+        for bounce in (0, 1, 2):
+            o, d, rng3 = path_rays(os_, oc, 3000, bounce)
+            want = os_.builder.intersect(o, d, 0.001, np.inf, rng3)
+            got = sim.intersect(o, d, 0.001, np.inf, rng3)
+            assert L.sim_wide_stretches() == BVH_CONFIGS[cfg]
+            assert L.sim_wide_steps() > 0
+            assert_hits_equal(got, want, exact=True, what=f"{cfg} bounce {bounce}")
+            assert got["counters"]["prim_tests"] <= want["counters"]["prim_tests"]
+    finally:
+        L.sim_set_walk_mode(0)
+
+
+@pytest.mark.parametrize("cfg", sorted(BVH_CONFIGS))
+def test_wide_trees_with_arbitrary_intervals_and_directions(pairs, cfg):
+    """Random origins, directions with zero components (1/d infinite in every slab test) and random finite
+    intervals, negative t included."""
+    hs, os_, sim = pairs(cfg)
+    L = _stretch_mode()
+    rs = np.random.RandomState(23)
+    n = 4000
+    lo, hi = (-15.0, 15.0) if cfg == "C1" else (-50.0, 600.0)
+    o = rs.uniform(lo, hi, (n, 3))
+    d = rs.standard_normal((n, 3))
+    d[::7, 0] = 0.0
+    d[::11, 1] = 0.0
+    d[::13, 2] = -0.0
+    o[::14] = np.round(o[::14])   # origins on round coordinates with axis-parallel directions: 0 * inf in the slabs
+    tmin = rs.uniform(-100.0, 10.0, n)
+    tmax = tmin + rs.uniform(0.0, 2000.0, n)
+    rng3 = np.stack([np.arange(n), np.full(n, 3), np.zeros(n)], axis=1).astype(np.uint32)
+    want = os_.builder.intersect(o, d, tmin, tmax, rng3)
+    L.sim_set_walk_mode(3)
+    try:
+        got = sim.intersect(o, d, tmin, tmax, rng3)
+    finally:
+        L.sim_set_walk_mode(0)
+    assert_hits_equal(got, want, exact=True, what=cfg)
+
+
+def test_wide_tree_over_mixed_leaves_and_fallback_for_other_trees():
+    """A BVH of spheres, quads, triangles and boxes in one list under an instance chain takes a wide tree (leaves are
+    runs of several kinds and box-shaped lists); a BVH whose objects are themselves instances or BVHs does not and
+    keeps the entry-by-entry walk.  Either way the hits are the oracle's."""
+    from oracle import oracle as orc
+    from raytracer_amd import HostBuilder
+    from raytracer_amd.philox import SceneRng
+
+    def make(b):
+        rng = SceneRng(321)
+        m = b.mat_lambertian(b.tex_solid(0.5, 0.5, 0.5))
+        lst = b.list_new()
+        for k in range(150):
+            c = rng.vector(-10.0, 10.0)
+            which = k % 4
+            if which == 0:
+                b.list_add(lst, b.sphere(c, rng.range(0.3, 1.5), m))
+            elif which == 1:
+                b.list_add(lst, b.quad(c, rng.vector(-2, 2), rng.vector(-2, 2), m))
+            elif which == 2:
+                b.list_add(lst, b.triangle(c, rng.vector(-2, 2), rng.vector(-2, 2), m))
+            else:
+                b.list_add(lst, b.slice(b.box(c, (c[0] + 1.0, c[1] + 2.0, c[2] + 0.5), m)))
+        inst = b.translate(b.rotate_y(b.bvh(lst), 33.0), (-3.0, 0.0, 4.0))
+        nested = b.list_new()   # objects of this BVH are translated spheres: chains change below the root
+        for k in range(40):
+            b.list_add(nested, b.translate(b.sphere(rng.vector(-8.0, 8.0), 0.8, m), (0.5, 0.0, 0.0)))
+        tris = b.list_new()
+        for k in range(90):
+            b.list_add(tris, b.triangle(rng.vector(-9.0, 9.0), rng.vector(-2, 2), rng.vector(-2, 2), m))
+        world = b.list_new()
+        b.list_add(world, b.quad((-30.0, -12.0, -30.0), (60.0, 0.0, 0.0), (0.0, 0.0, 60.0), m))
+        b.list_add(world, inst)
+        b.list_add(world, b.bvh(nested))
+        b.list_add(world, b.sphere((0.0, 0.0, 0.0), 1.0, m))
+        b.list_add(world, b.bvh(tris))
+        b.set_world(b.slice(world))
+
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    make(hb)
+    make(ob)
+    sim = HostSim(hb)
+    rs = np.random.RandomState(4)
+    n = 6000
+    o = rs.uniform(-25, 25, (n, 3))
+    d = -o + rs.uniform(-8, 8, (n, 3))
+    rng3 = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.uint32)
+    want = ob.intersect(o, d, 0.001, np.inf, rng3)
+    assert want["hit"].mean() > 0.5
+    L = _stretch_mode()
+    L.sim_set_walk_mode(3)
+    try:
+        got = sim.intersect(o, d, 0.001, np.inf, rng3)
+        assert L.sim_wide_stretches() == 2   # the mixed BVH and the triangle BVH; not the one over instances
+    finally:
+        L.sim_set_walk_mode(0)
+    assert_hits_equal(got, want, exact=True, what="mixed scene")
