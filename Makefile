@@ -3,9 +3,9 @@ HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 ARCH ?= gfx950
 CSRC := raytracer_amd/csrc
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -ffp-contract=off -fno-fast-math \
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wl,-Bsymbolic -ffp-contract=off -fno-fast-math \
             -Wall -Wno-unused-function -Iinclude
-HOSTFLAGS := -O2 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude
+HOSTFLAGS := -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude
 
 all: $(CSRC)/librt_amd.so $(CSRC)/librt_host.so oracle
 

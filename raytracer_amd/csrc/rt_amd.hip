@@ -332,7 +332,12 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
 // together; no random numbers are drawn here (no medium below such an entry).
 #define RT_WIDE_STEP_THRESHOLD 24
 #define RT_WIDE_FETCH_THRESHOLD 16
-__global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work) {
+// PROF: also adds up, per wavefront, the clock cycles spent handing out rays / in node steps / in primitive steps, the
+// number of each and the lanes that took part (development aid: RT_WIDE_PROF=1 prints the sums after a render).
+template <bool PROF>
+__global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work, unsigned long long* prof) {
+    unsigned long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = PROF ? clock64() : 0ull;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -352,6 +357,8 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide
         int n_node = __popcll(__ballot(ln.state == RT_W_NODE));
         int n_prim = __popcll(__ballot(ln.state == RT_W_PRIM));
         if (mask != 0ull && (__popcll(mask) >= RT_WIDE_FETCH_THRESHOLD || n_node + n_prim == 0)) {
+            const unsigned long long t0 = PROF ? clock64() : 0ull;
+            if (PROF) { pc[3]++; pc[6] += (unsigned long long)__popcll(mask); }
             if (need && idx != 0xFFFFFFFFu) {
                 a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
                 idx = 0xFFFFFFFFu;
@@ -383,11 +390,25 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide
             if (exhausted && __ballot(ln.state != RT_W_DONE) == 0ull) break;
             n_node = __popcll(__ballot(ln.state == RT_W_NODE));
             n_prim = __popcll(__ballot(ln.state == RT_W_PRIM));
+            if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[0] += clock64() - t0; }
         }
         const bool do_node = n_node >= RT_WIDE_STEP_THRESHOLD || n_node >= n_prim;
         const bool do_prim = n_prim >= RT_WIDE_STEP_THRESHOLD || n_prim > n_node;
-        if (do_node && ln.state == RT_W_NODE) wide_node_step(W, ln);
-        if (do_prim && ln.state == RT_W_PRIM) wide_prim_step<false>(S, W, ln, tally);
+        if (do_node) {
+            const unsigned long long t0 = PROF ? clock64() : 0ull;
+            if (ln.state == RT_W_NODE) wide_node_step(W, ln);
+            if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[1] += clock64() - t0; pc[4]++; pc[7] += (unsigned long long)n_node; }
+        }
+        if (do_prim) {
+            const unsigned long long t0 = PROF ? clock64() : 0ull;
+            if (ln.state == RT_W_PRIM) wide_prim_step<false>(S, W, ln, tally);
+            if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[2] += clock64() - t0; pc[5]++; pc[8] += (unsigned long long)n_prim; }
+        }
+    }
+    if (PROF && lane == 0) {
+        for (int k = 0; k < 9; ++k) atomicAdd(&prof[k], pc[k]);
+        atomicAdd(&prof[9], clock64() - t_begin);
+        atomicAdd(&prof[10], 1ull);
     }
 }
 
@@ -1239,6 +1260,10 @@ int rt_scene_commit(rt_scene* s, int device) {
         if ((rc = upload(s, w.refbox, &db))) return rc;
         dw.nodes = reinterpret_cast<const uint4*>(dn);
         dw.refbox = reinterpret_cast<const double2*>(db);
+        const uint32_t* di = nullptr;
+        if ((rc = upload(s, w.items, &di))) return rc;
+        dw.items = reinterpret_cast<const uint4*>(di);
+        for (int ax = 0; ax < 3; ++ax) { dw.base[ax] = w.base[ax]; dw.step[ax] = w.step[ax]; }
         dw.K = w.K; dw.lambda = w.lambda; dw.chain = w.chain;
         s->d_wide.push_back(dw);
     }
@@ -1288,6 +1313,7 @@ int rt_scene_commit(rt_scene* s, int device) {
     s->allocs.push_back(s->d_ring);
     HIP_TRY(hipHostMalloc((void**)&s->h_count, 1024, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&s->d_count, 1024));
+    HIP_TRY(hipMemset(s->d_count, 0, 1024));
     s->allocs.push_back(s->d_count);
     HIP_TRY(hipMalloc((void**)&s->d_tallies, 64));
     s->allocs.push_back(s->d_tallies);
@@ -1314,7 +1340,7 @@ int rt_scene_commit(rt_scene* s, int device) {
         }
         if (per_cu < 1) per_cu = 1;
         s->path_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_wide, TRAV_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_wide<false>, TRAV_BLOCK, 0));
         if (per_cu < 1) per_cu = 1;
         s->wide_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }
@@ -1371,9 +1397,12 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
                 a.wl_count = a_.wl_count + RT_COUNT_STRIDE * (4u + (uint32_t)st.wide);
             }
             HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
-            const uint32_t grid = std::min(waves, s->wide_waves);
+            static const uint32_t wdiv = getenv("RT_WIDE_DIV") ? (uint32_t)atoi(getenv("RT_WIDE_DIV")) : 1u;
+            const uint32_t grid = std::min(waves, s->wide_waves / wdiv);
             a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
-            hipLaunchKernelGGL(k_traverse_wide, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4);
+            static const bool prof = getenv("RT_WIDE_PROF") != nullptr;
+            if (prof) hipLaunchKernelGGL(k_traverse_wide<true>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3));
+            else hipLaunchKernelGGL(k_traverse_wide<false>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4, nullptr);
         } else if (st.kind == RT_STRETCH_LOCKSTEP) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
             if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
@@ -1809,6 +1838,20 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         st.prim_bytes = h[2];
         st.cull_tests = h[3];
         st.prim_flops = h[4];
+    }
+    if (getenv("RT_WIDE_PROF") != nullptr) {
+        unsigned long long h[64];
+        HIP_TRY(hipMemcpy(h, s->d_count + 64, sizeof h, hipMemcpyDeviceToHost));
+        for (size_t w = 0; w < std::min<size_t>(s->wide.size(), 4); ++w) {
+            const unsigned long long* p = h + 16 * w;
+            if (!p[10]) continue;
+            fprintf(stderr, "wide tree %zu: waves %llu, cycles/wave %.0f | hand-out: %.1f%% of cycles, %llu rounds, %.1f lanes, %.0f cycles each | "
+                    "node: %.1f%%, %llu steps, %.1f lanes, %.0f cycles | prim: %.1f%%, %llu steps, %.1f lanes, %.0f cycles\n", w, p[10],
+                    (double)p[9] / p[10], 100.0 * p[0] / p[9], p[3], (double)p[6] / std::max(1ull, p[3]), (double)p[0] / std::max(1ull, p[3]),
+                    100.0 * p[1] / p[9], p[4], (double)p[7] / std::max(1ull, p[4]), (double)p[1] / std::max(1ull, p[4]),
+                    100.0 * p[2] / p[9], p[5], (double)p[8] / std::max(1ull, p[5]), (double)p[2] / std::max(1ull, p[5]));
+        }
+        HIP_TRY(hipMemset(s->d_count + 64, 0, sizeof h));
     }
     if (stats) *stats = st;
     return RT_OK;

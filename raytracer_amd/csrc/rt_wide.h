@@ -31,9 +31,11 @@
 namespace rt {
 
 struct DWide {               // as the kernels see it
-    const uint4* nodes;      // 128 bytes per node: 4 x 6 f32 child boxes (x, y, z: start, end) | level-1 nodes only: the
-                             // four items as (first primitive, kind << 24 | count)
+    const uint4* nodes;      // 64 bytes per node, 48 used: the four child boxes, 6 x u16 each (x, y, z: start, end) on
+                             // the grid base + q * step of the tree's bounds, starts rounded down and ends up
+    const uint4* items;      // per level-1 node: its four items as (first primitive, kind << 24 | count)
     const double2* refbox;   // per leaf: the reference's box, 3 x (start, end)
+    double base[3], step[3]; // the grid
     uint32_t K;              // the root is node (K, 0)
     uint32_t lambda;         // a leaf covers 4^lambda item slots
     uint32_t chain;          // the instance chain the whole tree lives in
@@ -45,7 +47,9 @@ RT_HD uint32_t wide_node_index(uint32_t K, uint32_t k, uint32_t g) {
 // ---------------------------------------------------------------------------------------------------- host side
 struct WideBvh {
     uint32_t entry = 0, end = 0, chain = 0, K = 0, lambda = 0, leaves = 0;
-    std::vector<uint32_t> nodes;  // 32 words per node
+    std::vector<uint32_t> nodes;  // 16 words per node
+    std::vector<uint32_t> items;  // 8 words per level-1 node
+    double base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
     std::vector<double> refbox;   // 6 per leaf
     double bounds[6] = {0, 0, 0, 0, 0, 0};  // of everything below the entry (x, y, z: start, end), in its chain
 };
@@ -133,18 +137,6 @@ inline bool collect(Ctx& c, uint32_t e, int parent, int depth) {
     c.leaves.push_back(std::move(leaf));
     return true;
 }
-inline void outward(const double* box6, float* out6) {
-    if (!(box6[0] <= box6[1])) {  // empty: (inf, inf) fails the slab test whatever the ray
-        for (int k = 0; k < 6; ++k) out6[k] = std::numeric_limits<float>::infinity();
-        return;
-    }
-    for (int k = 0; k < 6; ++k) {
-        float f = (float)box6[k];
-        if (!(k & 1) && (double)f > box6[k]) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
-        if ((k & 1) && (double)f < box6[k]) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
-        out6[k] = f;
-    }
-}
 }  // namespace wide_detail
 
 // Builds the wide tree for the top-level BVH entry `root` (level 0).  False when the subtree is not of the shape
@@ -183,29 +175,57 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
             desc[2 * slot + 1] = it.kind << 24 | it.count;
         }
     }
-    const size_t total = (width - 1) / 3;
-    out.nodes.assign(32 * total, 0u);
-    size_t below = width;  // boxes in `cur` (level k - 1)
+    // every level's boxes first (the grid needs the bounds of the whole tree), then the records
+    std::vector<std::vector<double>> lv(K + 1);
+    lv[0].swap(cur);
     for (uint32_t k = 1; k <= K; ++k) {
-        const size_t count = below / 4;
-        std::vector<double> up(6 * count);
+        const size_t count = lv[k - 1].size() / 24;
+        lv[k].assign(6 * count, 0.0);
         for (size_t g = 0; g < count; ++g) {
-            uint32_t* rec = &out.nodes[32 * (size_t)wide_node_index(K, k, (uint32_t)g)];
             double u[6] = {inf, -inf, inf, -inf, inf, -inf};
             for (int j = 0; j < 4; ++j) {
-                const double* b = &cur[6 * (4 * g + j)];
-                float f[6];
-                outward(b, f);
-                std::memcpy(rec + 6 * j, f, 24);
+                const double* b = &lv[k - 1][6 * (4 * g + j)];
                 if (b[0] <= b[1]) for (int a = 0; a < 3; ++a) { u[2 * a] = std::min(u[2 * a], b[2 * a]); u[2 * a + 1] = std::max(u[2 * a + 1], b[2 * a + 1]); }
-                if (k == 1) { rec[24 + 2 * j] = desc[2 * (4 * g + j)]; rec[25 + 2 * j] = desc[2 * (4 * g + j) + 1]; }
             }
-            std::memcpy(&up[6 * g], u, 48);
+            std::memcpy(&lv[k][6 * g], u, 48);
         }
-        cur.swap(up);
-        below = count;
     }
-    std::memcpy(out.bounds, cur.data(), 48);
+    std::memcpy(out.bounds, lv[K].data(), 48);
+    for (int a = 0; a < 3; ++a) {
+        const double lo = out.bounds[2 * a], hi = out.bounds[2 * a + 1];
+        if (!(lo <= hi)) { out.base[a] = 0.0; out.step[a] = 1.0; continue; }  // nothing below the entry
+        if (!std::isfinite(lo) || !std::isfinite(hi)) return false;           // unbounded geometry: no grid
+        out.step[a] = std::max((hi - lo) / 65530.0, 1e-300);
+        out.base[a] = lo - 2.0 * out.step[a];
+        if (!std::isfinite(out.step[a]) || !std::isfinite(out.base[a])) return false;
+    }
+    const size_t total = (width - 1) / 3;
+    out.nodes.assign(16 * total, 0u);
+    out.items.assign(8 * (width / 4), 0u);
+    for (uint32_t k = 1; k <= K; ++k) {
+        const size_t count = lv[k].size() / 6;
+        for (size_t g = 0; g < count; ++g) {
+            uint16_t* rec = reinterpret_cast<uint16_t*>(&out.nodes[16 * (size_t)wide_node_index(K, k, (uint32_t)g)]);
+            for (int j = 0; j < 4; ++j) {
+                const double* b = &lv[k - 1][6 * (4 * g + j)];
+                for (int a = 0; a < 3; ++a) {
+                    uint16_t q0 = 65535, q1 = 65535;  // no child: a box without extent, which no interval can touch
+                    if (b[0] <= b[1]) {
+                        // largest grid point <= start, smallest >= end, checked against the values the walk computes
+                        double f0 = std::floor((b[2 * a] - out.base[a]) / out.step[a]), f1 = std::ceil((b[2 * a + 1] - out.base[a]) / out.step[a]);
+                        f0 = std::min(std::max(f0, 0.0), 65535.0); f1 = std::min(std::max(f1, 0.0), 65535.0);
+                        while (f0 > 0.0 && out.base[a] + f0 * out.step[a] > b[2 * a]) f0 -= 1.0;
+                        while (f1 < 65535.0 && out.base[a] + f1 * out.step[a] < b[2 * a + 1]) f1 += 1.0;
+                        if (out.base[a] + f0 * out.step[a] > b[2 * a] || out.base[a] + f1 * out.step[a] < b[2 * a + 1]) return false;
+                        // one more grid step either way: the walk evaluates these bounds in f32 (wide_box)
+                        q0 = (uint16_t)std::max(f0 - 1.0, 0.0); q1 = (uint16_t)std::min(f1 + 1.0, 65535.0);
+                    }
+                    rec[6 * j + 2 * a] = q0; rec[6 * j + 2 * a + 1] = q1;
+                }
+                if (k == 1) { out.items[8 * g + 2 * j] = desc[2 * (4 * g + j)]; out.items[8 * g + 2 * j + 1] = desc[2 * (4 * g + j) + 1]; }
+            }
+        }
+    }
     return true;
 }
 
@@ -242,6 +262,7 @@ inline std::vector<Stretch> build_stretches(const rt_node* nodes, uint32_t nn, b
 #define RT_W_DONE 2u
 struct WLane {
     Ray cur;                  // in the tree's chain, reciprocal direction ready
+    float ax, ay, az, bx, by, bz;  // grid value q of a child box -> ray parameter q * a + b, per axis (f32, see wide_box)
     uint32_t cur_chain;
     double tmin, tmax;        // the ray's interval at the top level
     double s, e;              // inside a leaf: the interval its box narrowed that to, e shortened by every hit since
@@ -252,9 +273,28 @@ struct WLane {
     uint32_t d0x, d0y, d1x, d1y, d2x, d2y, d3x, d3y;  // the items of the level-1 node above the cursor
     uint32_t state;
 };
+RT_HD bool wide_box(uint32_t wx, uint32_t wy, uint32_t wz, const WLane& ln, float s, float e) {
+    const float x0 = fmaf((float)(wx & 0xFFFFu), ln.ax, ln.bx), x1 = fmaf((float)(wx >> 16), ln.ax, ln.bx);
+    const float y0 = fmaf((float)(wy & 0xFFFFu), ln.ay, ln.by), y1 = fmaf((float)(wy >> 16), ln.ay, ln.by);
+    const float z0 = fmaf((float)(wz & 0xFFFFu), ln.az, ln.bz), z1 = fmaf((float)(wz >> 16), ln.az, ln.bz);
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), s));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), e));
+    return !(tf <= tn);
+}
 RT_HD void wide_begin(WLane& ln, const DScene& S, const DWide& W, const Ray& world, double tmin, double tmax, Best best) {
     ln.cur = ray_in_chain(S, world, W.chain);
     ray_need_inv(ln.cur);
+    ln.ax = (float)(W.step[0] * ln.cur.inv.x); ln.ay = (float)(W.step[1] * ln.cur.inv.y); ln.az = (float)(W.step[2] * ln.cur.inv.z);
+    ln.bx = (float)((W.base[0] - ln.cur.o.x) * ln.cur.inv.x); ln.by = (float)((W.base[1] - ln.cur.o.y) * ln.cur.inv.y);
+    ln.bz = (float)((W.base[2] - ln.cur.o.z) * ln.cur.inv.z);
+    // The f32 evaluation is off by at most 2^-23 (|grid offset| + |base - origin|) in space, which the extra grid step
+    // around every box (2^-16 of the tree's extent) covers as long as the origin is within ~100 extents of the tree;
+    // a ray from farther away leaves every axis undecided (NaN) and visits every node.
+    const double far = 100.0 * 65530.0;
+    if (!(fabs(W.base[0] - ln.cur.o.x) < far * W.step[0] && fabs(W.base[1] - ln.cur.o.y) < far * W.step[1] &&
+          fabs(W.base[2] - ln.cur.o.z) < far * W.step[2])) {
+        ln.bx = ln.by = ln.bz = __builtin_nanf("");
+    }
     ln.cur_chain = W.chain;
     ln.tmin = tmin; ln.tmax = tmax; ln.s = tmin; ln.e = tmax;
     ln.best = best;
@@ -264,17 +304,21 @@ RT_HD void wide_begin(WLane& ln, const DScene& S, const DWide& W, const Ray& wor
     ln.d0x = ln.d0y = ln.d1x = ln.d1y = ln.d2x = ln.d2y = ln.d3x = ln.d3y = 0u;
     ln.state = RT_W_NODE;
 }
-RT_HD void wide_item_start(WLane& ln, const DWide& W, uint32_t j) {
-    // picked with masks, not with ?: on the fields (which the compiler turns into a load through a selected
-    // address, and the whole lane state then lives in scratch memory)
+// Moves the cursor to child j of the level-k node above it: a node of level k - 1, or (k = 1) an item, whose run of
+// primitives starts.  Written without branches and with every field assigned on every path: fields stored in one
+// branch only end up addressed through a selected pointer, and the whole lane state then lives in scratch memory.
+RT_HD void wide_goto(WLane& ln, const DWide& W, uint32_t k, uint32_t j) {
+    ln.slot = ((ln.slot >> (2u * k)) << (2u * k)) | (j << (2u * (k - 1u)));
     const uint32_t m0 = j == 0u ? 0xFFFFFFFFu : 0u, m1 = j == 1u ? 0xFFFFFFFFu : 0u, m2 = j == 2u ? 0xFFFFFFFFu : 0u,
                    m3 = j == 3u ? 0xFFFFFFFFu : 0u;
     const uint32_t first = (ln.d0x & m0) | (ln.d1x & m1) | (ln.d2x & m2) | (ln.d3x & m3);
     const uint32_t kc = (ln.d0y & m0) | (ln.d1y & m1) | (ln.d2y & m2) | (ln.d3y & m3);
-    ln.kind = (kc >> 24) | (W.lambda == 0u ? 0x200u : 0u);
-    ln.k = first;
-    ln.kend = first + (kc & 0xFFFFFFu);
-    ln.state = RT_W_PRIM;
+    const bool item = k == 1u;
+    ln.kind = item ? ((kc >> 24) | (W.lambda == 0u ? 0x200u : 0u)) : ln.kind;
+    ln.k = item ? first : ln.k;
+    ln.kend = item ? first + (kc & 0xFFFFFFu) : ln.kend;
+    ln.level = k - 1u;
+    ln.state = item ? RT_W_PRIM : RT_W_NODE;
 }
 RT_HD uint32_t ctz64(unsigned long long x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -285,45 +329,49 @@ RT_HD uint32_t ctz64(unsigned long long x) {
 }
 // On to the nearest child still to be visited of the nodes above the cursor, or done.
 RT_HD void wide_ascend(WLane& ln, const DWide& W) {
-    if (ln.pending == 0ull) { ln.state = RT_W_DONE; return; }
-    const uint32_t p = ctz64(ln.pending);
-    ln.pending &= ln.pending - 1ull;
-    const uint32_t k = p >> 2, j = p & 3u;
-    ln.slot = ((ln.slot >> (2u * k)) << (2u * k)) | (j << (2u * (k - 1u)));
-    if (k == 1u) { wide_item_start(ln, W, j); return; }
-    ln.level = k - 1u;
-    ln.state = RT_W_NODE;
+    const bool none = ln.pending == 0ull;
+    const uint32_t p = none ? 4u : ctz64(ln.pending);
+    ln.pending &= ln.pending - 1ull;  // (0 stays 0)
+    wide_goto(ln, W, p >> 2, p & 3u);
+    ln.state = none ? RT_W_DONE : ln.state;
 }
-RT_HD bool wide_box(const float4 a, const float2 b, const Ray& r, double s, double e) {
-    double2 x, y, z;
-    x.x = a.x; x.y = a.y; y.x = a.z; y.y = a.w; z.x = b.x; z.y = b.y;
-    return slab3(x, y, z, r, s, e);
-}
+// Whether the ray's interval (s, e) may touch a child box, given as three words of two u16 grid values (x, y, z:
+// start | end << 16).  Nothing depends on the exact outcome -- a box is passed over only when this says it cannot be
+// touched -- so the test is written for speed: f32, one fused multiply-add per plane, no branches; the boxes are a grid
+// step wider than the geometry on every side for it (see wide_begin), and the caller rounds s down and e up.  A NaN
+// (0 * inf: a ray in a box's plane) drops out of min / max, which leaves that axis undecided: the box counts as touched.
+RT_HD bool wide_box(uint32_t wx, uint32_t wy, uint32_t wz, const WLane& ln, float s, float e);
 // One node for a lane in RT_W_NODE: the reference's narrowing when the node is a leaf's, then its four child boxes.
 RT_HD void wide_node_step(const DWide& W, WLane& ln) {
     const uint32_t k = ln.level;
-    const uint4* rp = W.nodes + 8u * wide_node_index(W.K, k, ln.slot >> (2u * k));
-    const float4* fp = reinterpret_cast<const float4*>(rp);
-    const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3], f4 = fp[4], f5 = fp[5];
+    const uint4* rp = W.nodes + 4u * wide_node_index(W.K, k, ln.slot >> (2u * k));
+    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
     if (k == 1u) {
-        const uint4 a = rp[6], b = rp[7];
+        const uint4* ip = W.items + 2u * (ln.slot >> 2);
+        const uint4 a = ip[0], b = ip[1];
         ln.d0x = a.x; ln.d0y = a.y; ln.d1x = a.z; ln.d1y = a.w; ln.d2x = b.x; ln.d2y = b.y; ln.d3x = b.z; ln.d3y = b.w;
     }
     if (W.lambda != 0u && k == W.lambda) {  // BVHNode::hit's box test for the leaf (bvh.rs:31-37)
         const double2* rb = W.refbox + 3u * (ln.slot >> (2u * W.lambda));
         const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keeps the compiler from sinking the loads into the slab test's branches, where each would wait on its own
+        asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x));
+#endif
         double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
         if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); return; }
         ln.s = s; ln.e = e;
     }
     const bool inside = k <= W.lambda;
-    const double cs = inside ? ln.s : ln.tmin, ce = fmin(inside ? ln.e : ln.tmax, ln.best.t);
-    float2 t;
+    const double ds = inside ? ln.s : ln.tmin, de = fmin(inside ? ln.e : ln.tmax, ln.best.t);
+    float cs = (float)ds, ce = (float)de;
+    cs = fmaf(-fabsf(cs), 1.1920929e-7f, cs);  // not above ds, not below de (an infinity stays one)
+    ce = fmaf(fabsf(ce), 1.1920929e-7f, ce);
     uint32_t m = 0u;
-    t.x = f1.x; t.y = f1.y; if (wide_box(f0, t, ln.cur, cs, ce)) m |= 1u;                                      // words 0..5
-    { float4 a; a.x = f1.z; a.y = f1.w; a.z = f2.x; a.w = f2.y; t.x = f2.z; t.y = f2.w; if (wide_box(a, t, ln.cur, cs, ce)) m |= 2u; }  // 6..11
-    t.x = f4.x; t.y = f4.y; if (wide_box(f3, t, ln.cur, cs, ce)) m |= 4u;                                      // 12..17
-    { float4 a; a.x = f4.z; a.y = f4.w; a.z = f5.x; a.w = f5.y; t.x = f5.z; t.y = f5.w; if (wide_box(a, t, ln.cur, cs, ce)) m |= 8u; }  // 18..23
+    if (wide_box(q0.x, q0.y, q0.z, ln, cs, ce)) m |= 1u;
+    if (wide_box(q0.w, q1.x, q1.y, ln, cs, ce)) m |= 2u;
+    if (wide_box(q1.z, q1.w, q2.x, ln, cs, ce)) m |= 4u;
+    if (wide_box(q2.y, q2.z, q2.w, ln, cs, ce)) m |= 8u;
     if (m == 0u) { wide_ascend(ln, W); return; }
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t j = (uint32_t)(__ffs((int)m) - 1);
@@ -332,9 +380,7 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln) {
 #endif
     m &= m - 1u;
     ln.pending |= (unsigned long long)m << (4u * k);
-    ln.slot = ((ln.slot >> (2u * k)) << (2u * k)) | (j << (2u * (k - 1u)));
-    if (k == 1u) { wide_item_start(ln, W, j); return; }
-    ln.level = k - 1u;
+    wide_goto(ln, W, k, j);
 }
 // The next primitives of the run in progress for a lane in RT_W_PRIM (lane_prim_tests: two planar primitives or four
 // spheres per step).
@@ -344,6 +390,10 @@ RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tal
         ln.kind &= ~0x200u;
         const double2* rb = W.refbox + 3u * ln.slot;
         const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keeps the compiler from sinking the loads into the slab test's branches, where each would wait on its own
+        asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x));
+#endif
         double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
         if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); return; }
         ln.s = s; ln.e = e;

@@ -56,10 +56,11 @@ def _sim_lib():
         src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
         deps = [src] + [os.path.join(ROOT, *p) for p in (("raytracer_amd", "csrc", "rt_core.h"),
                                                          ("raytracer_amd", "csrc", "rt_records.h"),
+                                                         ("raytracer_amd", "csrc", "rt_wide.h"),
                                                          ("include", "rt_amd.h"))]
         if not os.path.exists(so) or os.path.getmtime(so) <= max(os.path.getmtime(d) for d in deps):
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-host-only", "-x", "hip", "-O2", "-std=c++17", "-fPIC",
-                                   "-shared", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", so, src])
+                                   "-shared", "-Wl,-Bsymbolic", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", so, src])
         _SIM = C.CDLL(so)
     return _SIM
 

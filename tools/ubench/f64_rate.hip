@@ -25,6 +25,11 @@ __global__ void __launch_bounds__(64) k(double* out, int iters, double seed) {
             if (OP == 6) a[j] = sqrt(a[j]);
             if (OP == 7) a[j] = a[j] / b;
             if (OP == 8) u[j] = (u[j] ^ (u[j] >> 3)) + 0x9E3779B9u;
+            if (OP == 9) a[j] = __builtin_fmin(a[j], b + a[(j + 1) & 7]);           // add + min
+            if (OP == 10) a[j] = a[j] + (double)u[j];                                // cvt_f64_u32 + add
+            if (OP == 11) a[j] = a[j] + (double)f[j];                                // cvt_f64_f32 + add
+            if (OP == 12) a[j] = a[j] < b ? a[j] + c : a[j];                         // cmp + cndmask x2 + add
+            if (OP == 13) f[j] = __builtin_fminf(f[j], fb + f[(j + 1) & 7]);         // f32 add + min
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
@@ -58,11 +63,13 @@ void run(const char* name, int waves_per_simd, int ops_per_iter) {
     CHECK(hipFree(d));
 }
 int main() {
-    const int ws[5] = {1, 2, 3, 4, 8};
-    for (int wi = 0; wi < 5; ++wi) {
+    const int ws[2] = {1, 4};
+    for (int wi = 0; wi < 2; ++wi) {
         const int w = ws[wi];
         run<0>("fma_f64", w, 1); run<2>("add_f64", w, 1); run<3>("fma_f32", w, 1);
         run<4>("mad_u64_u32+xor", w, 1); run<7>("x/b f64", w, 1); run<6>("sqrt f64", w, 1);
+        run<9>("add+min f64", w, 1); run<10>("cvt_u32+add f64", w, 1); run<11>("cvt_f32+add f64", w, 1);
+        run<12>("cmp+sel+add f64", w, 1); run<13>("add+min f32", w, 1);
     }
     return 0;
 }
