@@ -5,12 +5,19 @@ depth -> film accumulation, plus the film all-reduce when N > 1) of a BASELINE.j
   python bench.py --gpus 1 --steps K --warmup W            # default workload: configs[1] (cornell_smoke 600px 200spp)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Weak scaling: every rank renders the configuration's full sample count on its own range of global sample indices
-(rank r renders samples [r*spp, (r+1)*spp)), then the f64 films are summed with one RCCL all-reduce; the job has
-rendered N*spp samples per pixel.  Rank 0 prints one JSON line."""
+Scaling.  Default is weak: every rank renders the configuration's full sample count on its own range of global sample
+indices (rank r renders samples [r*spp, (r+1)*spp)), so the job has rendered N*spp samples per pixel.  `--scaling
+strong` keeps the configuration's sample count for the whole job and gives rank r its contiguous share of it
+(raytracer_amd.dist.shard_range; the reference's precedent is thrender_no_rayon, camera.rs:319-328).  Either way the
+f64 films are summed with one RCCL all-reduce and rank 0 prints one JSON line.
+
+At N = 1 the line also carries, under "also", the same measurement for the BVH workloads the headline configuration
+does not exercise (C4 at its full size, C5 at a stated reduced sample count), each timed after the headline's timed
+region, with its own roofline and CPU baseline."""
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -20,32 +27,230 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {  # BASELINE.json configs -> (scene function key, width, spp)
     "C1": ("C1", 400, 10), "C2": ("C2", 600, 200), "C3": ("C3", 600, 1000), "C4": ("C4", 800, 2000), "C5": ("C5", 800, 10000),
 }
-S_NODE, S_STATE, S_HIT = 64, 88, 56  # algorithmic bytes: BVH entry, path state, hit record
+S_NODE, S_STATE, S_HIT = 64, 88, 56  # bytes of a BVH entry, a path state, a hit record in the reference's terms
 HBM_PEAK_GBS = 8000.0
-FP64_PEAK_TFLOPS = 78.6
+FP64_PEAK_TFLOPS = 78.6   # vector FP64 peak of one MI355X (an FMA counted as two flops)
+FLOPS_BOX, FLOPS_SHADE = 18.0, 100.0  # algorithmic flops of one slab test / of shading one bounce
 
 
-def cpu_baseline(config, width, max_seconds=20.0):
+def host_cpu():
+    """(model name, logical CPUs of the machine, CPUs this process may run on)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical
+    return model, logical, usable
+
+
+def cpu_baseline(config, width, max_seconds=18.0):
     """Times the CPU oracle (C++ restatement of the reference, a thread pool over rows standing in for Rayon) on a
-    bounded sample of the same workload: same scene and resolution, fewer samples per pixel."""
+    bounded sample of the same workload: same scene and resolution, fewer samples per pixel.  All CPUs this process may
+    run on (median of three runs), and one thread beside it."""
     from oracle import oracle as orc
     from raytracer_amd import scenes
     spec = scenes.build(config, orc.OracleBuilder(), width=width)
     cam = orc.camera_new(image_width=width, **spec.camera)
-    cores = min(16, os.cpu_count() or 1)
-    t0 = time.time()
-    _, st = spec.builder.render(cam, 1, spec.max_depth, spec.background, threads=cores)
-    dt = time.time() - t0
-    spp = 1
-    if dt < max_seconds / 3:
-        spp = max(1, min(64, int(max_seconds / max(dt, 1e-3)) - 1))
+    model, logical, usable = host_cpu()
+    threads = max(1, usable)
+
+    def timed(spp, begin, nthreads):
         t0 = time.time()
-        _, st = spec.builder.render(cam, spp, spec.max_depth, spec.background, spp_begin=1, threads=cores)
-        dt = time.time() - t0
-    return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "mpaths_per_s": st["paths"] / dt / 1e6,
+        _, st = spec.builder.render(cam, spp, spec.max_depth, spec.background, spp_begin=begin, threads=nthreads)
+        return st, time.time() - t0
+
+    st, dt = timed(1, 0, threads)                      # sizes the sample: about a quarter of the budget per run
+    spp = max(1, min(64, int(max_seconds / 4.0 / max(dt, 1e-3))))
+    runs = []
+    for k in range(3):
+        st, dt = timed(spp, 1 + k * spp, threads)
+        runs.append((st["rays"] / dt / 1e6, st["paths"] / dt / 1e6, st["rays"], dt))
+    runs.sort()
+    rate, prate, rays, dt = runs[1]
+    # one thread: a row band's worth of the same image is not available through the oracle's interface, so the whole
+    # image at 1 spp when that fits the budget, else reported as not measured
+    one = None
+    if dt / spp * threads < max_seconds:               # estimated single-thread time of 1 spp
+        st1, dt1 = timed(1, 0, 1)
+        one = st1["rays"] / dt1 / 1e6
+    return {"value": rate, "unit": "Mrays/s", "cores": threads, "kind": "port", "mpaths_per_s": prate,
+            "value_1thread": one, "cpu_model": model, "host_logical_cpus": logical, "usable_cpus": usable,
+            "runs_mrays_per_s": [r[0] for r in runs],
             "sample": f"{spec.name} {cam.width}x{cam.height}, {spp} spp of the workload's samples, depth {spec.max_depth}, "
-                      f"{st['rays']} rays in {dt:.1f} s; C++ restatement of the reference, not Rayon"}
+                      f"{rays} rays in {dt:.1f} s on {threads} threads (median of 3); C++ restatement of the reference, not Rayon"}
+
+
+def profiled(config):
+    """What profiles/traffic.json holds for this workload (written by tools/make_traffic.py from rocprofv3 passes of
+    this same command): HBM bytes per ray of the dominant kernel and the profiled VALU issue account."""
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tj):
+        return {}
+    with open(tj) as fh:
+        return json.load(fh).get(config, {})
+
+
+def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_rank, world, with_cpu):
+    """Times `steps` renders of one workload; returns the JSON fields of that workload (rank 0) or None."""
+    from raytracer_amd import HostBuilder, camera_new, scenes
+    from raytracer_amd.dist import render_sharded, shard_range
+    if config in WORKLOADS:
+        key, width, spp = WORKLOADS[config]
+    elif config in scenes.SCENES:
+        probe = scenes.build(config, HostBuilder())
+        key, width, spp = config, probe.width, probe.spp
+        probe.builder.close()
+    else:
+        raise SystemExit(f"unknown --config {config}: one of {sorted(WORKLOADS)} or {sorted(scenes.SCENES)}")
+    width = args.width or width
+    spp = spp_override or spp
+    spec = scenes.build(key, HostBuilder(), width=width)
+    cam = camera_new(image_width=width, **spec.camera)
+    scene = spec.builder.commit(local_rank)
+    film = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
+    schedule = True if args.whole_paths else (False if args.queues else None)
+    strong = args.scaling == "strong"
+    spp_job = spp if strong else spp * world
+
+    def step():
+        st = {}
+
+        def render_range(begin, count):
+            st.update(scene.render_into(cam, count, spec.max_depth, spec.background, film.data_ptr(), spp_begin=begin,
+                                        batch_paths=args.batch_paths, whole_paths=schedule,
+                                        split_bounce=args.split_bounce))
+
+        render_sharded(render_range, film, spp_job)  # this rank's contiguous share of the job's samples, then all-reduce
+        return st
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(steps):
+        stats.append(step())
+    fence()
+    elapsed = time.perf_counter() - t0
+    stats = [s for s in stats if s]  # (a rank whose share of a strong-scaling job is empty renders nothing)
+    rays_local = float(sum(s["rays"] for s in stats))
+    paths_local = float(sum(s["paths"] for s in stats))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([rays_local, paths_local], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tot)
+        total_rays, total_paths = float(tot[0].item()), float(tot[1].item())
+    else:
+        total_rays, total_paths = rays_local, paths_local
+    if rank != 0:
+        scene.close()
+        return None
+
+    out = {
+        "metric": "Mrays/s", "value": total_rays / elapsed / 1e6 if elapsed > 0 else 0.0, "unit": "Mrays/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / max(steps, 1) * 1e3,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "mpaths_per_s": total_paths / elapsed / 1e6 if elapsed > 0 else 0.0,
+        "config": {"workload": f"{config} {spec.name} {cam.width}x{cam.height}, "
+                               f"{spp_job} spp in all ({shard_range(spp_job, 0, world)[1]} on rank 0), depth {spec.max_depth}",
+                   "spp_total": spp_job, "paths_per_step": int(total_paths / max(steps, 1)), "seed": 42,
+                   "parallelism": f"spp-shard x{world}" if world > 1 else "single GPU"},
+    }
+    # Per-ray work of this workload from the device counters (untimed passes at reduced spp): with the cull boxes off
+    # the box and primitive tests are exactly the reference algorithm's ("algorithmic"); with them on, what the timed
+    # steps really execute ("executed").
+    cspp = max(1, min(spp, 4))
+    ref = scene.render_into(cam, cspp, spec.max_depth, spec.background, film.data_ptr(), counters=True, cull=False)
+    done = scene.render_into(cam, cspp, spec.max_depth, spec.background, film.data_ptr(), counters=True)
+    n_node = ref["node_tests"] / ref["rays"]
+    prim_bytes = ref["prim_bytes"] / ref["rays"]
+    flops_alg = FLOPS_BOX * n_node + ref["prim_flops"] / ref["rays"] + FLOPS_SHADE
+    flops_exec = FLOPS_BOX * (done["node_tests"] + done["cull_tests"]) / done["rays"] + done["prim_flops"] / done["rays"] + FLOPS_SHADE
+    b_ray = S_NODE * n_node + prim_bytes + 2 * S_STATE + 2 * S_HIT
+    # the dominant kernel (or, for trees with BVH entries, the launches of the traverse phase of one bounce) and its
+    # mean duration, measured with HIP events on the library's stream during the timed steps
+    whole = True   # the kernel does whole bounces (walk + shade), so a ray's whole flop count is its work
+    if not stats:
+        kernel, launches, ms_kernel = "none", 0, 0.0
+    elif sum(s["path_launches"] for s in stats) > 0:
+        kernel, launches, ms_kernel = "k_paths_lockstep", sum(s["path_launches"] for s in stats), sum(s["ms_paths"] for s in stats)
+    elif sum(s["bounce_launches"] for s in stats) > 0:
+        kernel, launches, ms_kernel = "k_bounce_lockstep", sum(s["bounce_launches"] for s in stats), sum(s["ms_bounce"] for s in stats)
+    elif sum(s["traverse_launches"] for s in stats) > 0:
+        whole = False
+        kernel = "k_traverse_lockstep" if stats[0]["lockstep"] else "traverse phase of a bounce (k_traverse_lockstep / k_traverse_wide / k_traverse_persistent, one launch per stretch of the tree)"
+        launches, ms_kernel = sum(s["traverse_launches"] for s in stats), sum(s["ms_traverse"] for s in stats)
+    else:  # so small a workload that the tail kernel took all of it
+        kernel, launches, ms_kernel = "k_finish", sum(s["finish_launches"] for s in stats), sum(s["ms_finish"] for s in stats)
+    if launches > 0 and ms_kernel > 0:
+        avg_ms = ms_kernel / launches
+        rays_per_launch = rays_local / launches
+        shade = 0.0 if whole else FLOPS_SHADE
+        alg = rays_per_launch * (flops_alg - shade) / (avg_ms * 1e-3) / 1e12
+        exe = rays_per_launch * (flops_exec - shade) / (avg_ms * 1e-3) / 1e12
+        prof = profiled(config)
+        roof = {"bound": "fp64 valu", "kernel": kernel, "achieved": alg, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": alg / FP64_PEAK_TFLOPS, "frac_algorithmic": alg / FP64_PEAK_TFLOPS, "frac_executed": exe / FP64_PEAK_TFLOPS,
+                "achieved_executed": exe, "flops_per_ray_algorithmic": flops_alg, "flops_per_ray_executed": flops_exec,
+                "avg_launch_ms": avg_ms, "launches": launches, "rays_per_launch": rays_per_launch,
+                "kernel_share_of_step": ms_kernel / (elapsed * 1e3),
+                "shade_ms_per_step": sum(s["ms_shade"] for s in stats) / max(steps, 1),
+                "traffic": None,
+                "note": "algorithmic = the reference's test counts (18 flops per box test; 35 / 60 / 70 / 30 per sphere / "
+                        "planar / quadric / medium test; 100 per bounce shaded), executed = the tests the timed kernels do "
+                        "after culling; FMA contraction is off, so half of the peak is the ceiling for this arithmetic",
+                "work_per_ray": {"reference_node_tests": n_node, "reference_prim_tests": ref["prim_tests"] / ref["rays"],
+                                 "executed_node_tests": done["node_tests"] / done["rays"],
+                                 "executed_cull_tests": done["cull_tests"] / done["rays"],
+                                 "executed_prim_tests": done["prim_tests"] / done["rays"]},
+                "cache_served_bytes_per_ray": b_ray}
+        if prof.get("valu_issue"):
+            roof["valu_issue_profiled"] = prof["valu_issue"]
+        hbm = None
+        bpr = prof.get("hbm_bytes_per_ray")
+        if bpr and prof.get("kernel", "").split("<")[0].split(" ")[0] == kernel.split(" ")[0]:
+            traffic = bpr * rays_per_launch
+            roof["traffic"] = traffic
+            gbs = traffic / (avg_ms * 1e-3) / 1e9
+            hbm = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                   "traffic": traffic, "bytes_per_ray": bpr,
+                   "source": "rocprofv3 FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of this command, per ray of the profiled run "
+                             "(profiles/traffic.json) x the rays of a launch here"}
+        if roof["frac_algorithmic"] > 1.0:
+            # the reference algorithm's flop count is not this hardware's work when most of its tests are culled (trees
+            # with BVH entries): the fraction of the peak is then the executed one
+            roof["frac"], roof["achieved"] = roof["frac_executed"], exe
+            roof["frac_is"] = "executed (the algorithmic figure exceeds the peak: culled tests are not hardware work)"
+        for r in (roof, hbm):
+            if r is not None and not (0.0 <= r["frac"] <= 1.0):  # a fraction above 1 would be a modelling error: not reported
+                r["frac_rejected"] = r["frac"]
+                r["frac"] = None
+        out["roofline"] = roof
+        if hbm is not None:
+            out["roofline_hbm"] = hbm
+    else:
+        out["roofline"] = None
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(key, width)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
+    scene.close()
+    return out
 
 
 def main():
@@ -55,10 +260,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C2", help="a BASELINE.json configuration (C1..C5, the metric's workloads) or the "
                     "name of another scene program of the reference, run at the reference's own settings")
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per GPU (invalidates the metric)")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the metric)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the BVH workloads timed after the headline one")
+    ap.add_argument("--also-c5-spp", type=int, default=1000, help="samples per pixel of the C5 entry under \"also\"")
     ap.add_argument("--whole-paths", action="store_true", help="RT_FLAG_WHOLE_PATHS: one kernel per batch (BVH-free scenes)")
     ap.add_argument("--queues", action="store_true", help="RT_FLAG_QUEUES: the queue-based schedule whatever the scene")
     ap.add_argument("--split-bounce", action="store_true", help="RT_FLAG_SPLIT_BOUNCE: separate traverse and shade launches")
@@ -76,127 +284,16 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from raytracer_amd import HostBuilder, camera_new, scenes
-    if args.config in WORKLOADS:
-        key, width, spp = WORKLOADS[args.config]
-    elif args.config in scenes.SCENES:
-        probe = scenes.build(args.config, HostBuilder())
-        key, width, spp = args.config, probe.width, probe.spp
-        probe.builder.close()
-    else:
-        raise SystemExit(f"unknown --config {args.config}: one of {sorted(WORKLOADS)} or {sorted(scenes.SCENES)}")
-    width = args.width or width
-    spp = args.spp or spp
-    spec = scenes.build(key, HostBuilder(), width=width)
-    cam = camera_new(image_width=width, **spec.camera)
-    scene = spec.builder.commit(local_rank)
-    film = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
-
-    from raytracer_amd.dist import render_sharded
-
-    schedule = True if args.whole_paths else (False if args.queues else None)
-
-    def step():
-        st = {}
-
-        def render_range(begin, count):
-            st.update(scene.render_into(cam, count, spec.max_depth, spec.background, film.data_ptr(), spp_begin=begin,
-                                        batch_paths=args.batch_paths, whole_paths=schedule,
-                                        split_bounce=args.split_bounce))
-
-        render_sharded(render_range, film, spp * world)  # rank r renders samples [r*spp, (r+1)*spp), then RCCL all-reduce
-        return st
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        stats.append(step())
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([sum(s["rays"] for s in stats), sum(s["paths"] for s in stats)], dtype=torch.float64,
-                           device=f"cuda:{local_rank}")
-        dist.all_reduce(tot)
-        total_rays, total_paths = float(tot[0].item()), float(tot[1].item())
-    else:
-        total_rays, total_paths = float(sum(s["rays"] for s in stats)), float(sum(s["paths"] for s in stats))
-
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    out = measure(args, args.config, args.spp, args.steps, args.warmup, torch, dist, rank, local_rank, world, with_cpu)
+    if world == 1 and not args.no_also and args.config == "C2" and not args.spp and not args.width:
+        also = []
+        for cfg, spp, steps in (("C4", 0, 2), ("C5", args.also_c5_spp, 2)):
+            r = measure(args, cfg, spp, steps, 1, torch, dist, rank, local_rank, world, with_cpu)
+            r["valid_metric_line"] = spp == 0  # (C5 runs at a reduced sample count: a rate, not the configuration's line)
+            also.append(r)
+        out["also"] = also
     if rank == 0:
-        # per-ray algorithmic work of this workload, from the device counters (one untimed pass at reduced spp)
-        # with the cull boxes off, i.e. the box and primitive tests the reference's algorithm performs; the timed
-        # steps skip part of that work (cull boxes), which is reported beside it
-        cst = scene.render_into(cam, min(spp, 4), spec.max_depth, spec.background, film.data_ptr(), counters=True,
-                                cull=False)
-        n_node = cst["node_tests"] / cst["rays"]
-        prim_bytes = cst["prim_bytes"] / cst["rays"]
-        dst = scene.render_into(cam, min(spp, 4), spec.max_depth, spec.background, film.data_ptr(), counters=True)
-        done = {"node_visits_per_ray": dst["node_tests"] / dst["rays"], "cull_tests_per_ray": dst["cull_tests"] / dst["rays"],
-                "prim_tests_per_ray": dst["prim_tests"] / dst["rays"], "prim_bytes_per_ray": dst["prim_bytes"] / dst["rays"],
-                "reference_prim_tests_per_ray": cst["prim_tests"] / cst["rays"]}
-        # algorithmic flops per ray: 18 per box test, the primitive tests as counted, ~100 for shading one bounce
-        flops_ray = 18.0 * n_node + cst["prim_flops"] / cst["rays"] + 100.0
-        b_trav = S_NODE * n_node + prim_bytes + S_STATE + S_HIT        # traverse+intersect launch
-        b_ray = S_NODE * n_node + prim_bytes + 2 * S_STATE + 2 * S_HIT  # whole bounce
-        rays_local = sum(s["rays"] for s in stats)
-        fused = sum(s["path_launches"] for s in stats) > 0
-        if fused:  # whole paths in one kernel: the dominant kernel does the whole bounce
-            kernel = "k_paths_lockstep"
-            launches, ms_trav, b_kernel = sum(s["path_launches"] for s in stats), \
-                sum(s["ms_paths"] for s in stats), b_ray
-        elif sum(s["bounce_launches"] for s in stats) > 0:  # traverse + shade of one bounce in one kernel
-            kernel = "k_bounce_lockstep"
-            launches, ms_trav, b_kernel = sum(s["bounce_launches"] for s in stats), \
-                sum(s["ms_bounce"] for s in stats), b_ray
-        else:
-            kernel = "k_traverse_lockstep" if stats[0]["lockstep"] else "k_traverse_persistent"
-            launches, ms_trav, b_kernel = sum(s["traverse_launches"] for s in stats), \
-                sum(s["ms_traverse"] for s in stats), b_trav
-        if launches == 0:  # so small a workload that the tail kernel took all of it
-            kernel = "k_finish"
-            launches, ms_trav, b_kernel = sum(s["finish_launches"] for s in stats), sum(s["ms_finish"] for s in stats), b_ray
-        avg_launch_ms = ms_trav / launches
-        achieved = (rays_local / launches) * b_kernel / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            with open(tj) as fh:
-                traffic = json.load(fh).get(args.config, {}).get(kernel + "_hbm_bytes_per_launch")
-        out = {
-            "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "mpaths_per_s": total_paths / elapsed / 1e6,
-            "config": {"workload": f"{args.config} {spec.name} {cam.width}x{cam.height}, {spp} spp per GPU, depth {spec.max_depth}",
-                       "spp_total": spp * world, "paths_per_step": int(total_paths / args.steps), "seed": 42,
-                       "parallelism": f"spp-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray_kernel": b_kernel, "bytes_per_ray_traverse": b_trav, "bytes_per_ray_bounce": b_ray, "node_tests_per_ray": n_node,
-                         "prim_bytes_per_ray": prim_bytes, "avg_launch_ms": avg_launch_ms, "launches": launches,
-                         "traverse_share_of_step": ms_trav / (elapsed * 1e3),
-                         "shade_ms_per_step": sum(s["ms_shade"] for s in stats) / args.steps,
-                         "work_done_with_cull_boxes": done},
-            # the bound that actually binds (all scenes are cache-resident): whole-step algorithmic flops against
-            # the FP64 vector peak, which counts an FMA as two flops although contraction is not allowed here
-            "roofline_fp64": {"bound": "fp64 valu", "achieved": total_rays / elapsed * flops_ray / 1e12 / world,
-                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
-                              "frac": total_rays / elapsed * flops_ray / 1e12 / world / FP64_PEAK_TFLOPS,
-                              "flops_per_ray": flops_ray},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(key, width)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

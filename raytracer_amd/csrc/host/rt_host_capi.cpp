@@ -31,6 +31,7 @@ static int bad(rth_builder* b, const char* what) {
     b->err = what;
     return -1;
 }
+#define NEEDB if (!b) return -1
 #define TEX(i) if ((i) < 0 || (size_t)(i) >= b->textures.size()) return bad(b, "texture handle out of range")
 #define MAT(i) if ((i) < 0 || (size_t)(i) >= b->materials.size()) return bad(b, "material handle out of range")
 #define OBJ(i) if ((i) < 0 || (size_t)(i) >= b->objects.size()) return bad(b, "object handle out of range")
@@ -40,6 +41,9 @@ static int bad(rth_builder* b, const char* what) {
         body                                 \
     } catch (const std::exception& e) {      \
         b->err = e.what();                   \
+        return -1;                           \
+    } catch (...) {                          \
+        b->err = "unexpected failure";       \
         return -1;                           \
     }
 static int push_tex(rth_builder* b, TexturePtr t) { b->textures.push_back(t); return (int)b->textures.size() - 1; }
@@ -52,99 +56,109 @@ rth_builder* rth_new(void) { return new (std::nothrow) rth_builder(); }
 void rth_free(rth_builder* b) { delete b; }
 const char* rth_error(rth_builder* b) { return b ? b->err.c_str() : "null builder"; }
 
-int rth_tex_solid(rth_builder* b, double r, double g, double bl) { return push_tex(b, SolidColor::create(Color(r, g, bl))); }
+int rth_tex_solid(rth_builder* b, double r, double g, double bl) { NEEDB; GUARD(return push_tex(b, SolidColor::create(Color(r, g, bl)));) }
 int rth_tex_checker(rth_builder* b, double scale, int even, int odd) {
-    TEX(even); TEX(odd);
-    return push_tex(b, CheckerTexture::from_pointers(scale, b->textures[even], b->textures[odd]));
+    NEEDB; TEX(even); TEX(odd);
+    GUARD(return push_tex(b, CheckerTexture::from_pointers(scale, b->textures[even], b->textures[odd]));)
 }
 int rth_tex_image(rth_builder* b, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+    NEEDB;
     if (!rgb8 || !w || !h) return bad(b, "empty image");
-    return push_tex(b, ImageTexture::from_rgb8(rgb8, w, h));
+    GUARD(return push_tex(b, ImageTexture::from_rgb8(rgb8, w, h));)
 }
-int rth_tex_image_file(rth_builder* b, const char* path) { return push_tex(b, ImageTexture::new_or_fallback(path)); }
+int rth_tex_image_file(rth_builder* b, const char* path) {
+    NEEDB;
+    if (!path) return bad(b, "null path");
+    GUARD(return push_tex(b, ImageTexture::new_or_fallback(path));)
+}
 int rth_tex_perlin(rth_builder* b, double scale, const double* draws768) {
+    NEEDB;
     if (!draws768) return bad(b, "null perlin draws");
-    return push_tex(b, PerlinNoiseTexture::create(create_perlin_noise(draws768), scale));
+    GUARD(return push_tex(b, PerlinNoiseTexture::create(create_perlin_noise(draws768), scale));)
 }
-int rth_mat_lambertian(rth_builder* b, int tex) { TEX(tex); return push_mat(b, Lambertian::from_texture(b->textures[tex])); }
-int rth_mat_metal(rth_builder* b, double r, double g, double bl, double fuzz) { return push_mat(b, metal(Color(r, g, bl), fuzz)); }
-int rth_mat_dielectric(rth_builder* b, double ri) { return push_mat(b, dielectric(ri)); }
-int rth_mat_diffuse_light(rth_builder* b, int tex) { TEX(tex); return push_mat(b, DiffuseLight::from_texture(b->textures[tex])); }
+int rth_mat_lambertian(rth_builder* b, int tex) { NEEDB; TEX(tex); GUARD(return push_mat(b, Lambertian::from_texture(b->textures[tex]));) }
+int rth_mat_metal(rth_builder* b, double r, double g, double bl, double fuzz) { NEEDB; GUARD(return push_mat(b, metal(Color(r, g, bl), fuzz));) }
+int rth_mat_dielectric(rth_builder* b, double ri) { NEEDB; GUARD(return push_mat(b, dielectric(ri));) }
+int rth_mat_diffuse_light(rth_builder* b, int tex) { NEEDB; TEX(tex); GUARD(return push_mat(b, DiffuseLight::from_texture(b->textures[tex]));) }
 int rth_mat_isotropic(rth_builder* b, int tex) {
-    TEX(tex);
-    auto m = std::make_shared<Isotropic>();
-    m->texture = b->textures[tex];
-    return push_mat(b, m);
+    NEEDB; TEX(tex);
+    GUARD(auto m = std::make_shared<Isotropic>();
+          m->texture = b->textures[tex];
+          return push_mat(b, m);)
 }
 int rth_sphere(rth_builder* b, const double* c, double r, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
     GUARD(return push_obj(b, std::make_shared<Sphere>(p3(c), r, b->materials[mat]));)
 }
 int rth_quad(rth_builder* b, const double* q, const double* u, const double* v, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
     GUARD(return push_obj(b, std::make_shared<Parallelogram>(p3(q), p3(u), p3(v), b->materials[mat]));)
 }
 int rth_triangle(rth_builder* b, const double* q, const double* u, const double* v, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
     GUARD(return push_obj(b, std::make_shared<Triangle>(p3(q), p3(u), p3(v), b->materials[mat]));)
 }
 int rth_y_cylinder(rth_builder* b, const double* c, double r, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
     GUARD(return push_obj(b, y_cylinder(p3(c), r, b->materials[mat]));)
 }
 int rth_quadric_sphere(rth_builder* b, const double* c, double r, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
     GUARD(return push_obj(b, quadric_sphere(p3(c), r, b->materials[mat]));)
 }
 int rth_y_cone(rth_builder* b, const double* c, const double* off, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
     GUARD(return push_obj(b, y_cone(p3(c), p3(off), b->materials[mat]));)
 }
-int rth_list_new(rth_builder* b) { b->lists.emplace_back(); return (int)b->lists.size() - 1; }
+int rth_list_new(rth_builder* b) { NEEDB; GUARD(b->lists.emplace_back(); return (int)b->lists.size() - 1;) }
 int rth_list_add(rth_builder* b, int list, int obj) {
-    LST(list); OBJ(obj);
+    NEEDB; LST(list); OBJ(obj);
     GUARD(b->lists[list].add_pointer(b->objects[obj]); return 0;)
 }
 int rth_box(rth_builder* b, const double* a, const double* c, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
     GUARD(b->lists.push_back(create_box(p3(a), p3(c), b->materials[mat])); return (int)b->lists.size() - 1;)
 }
-int rth_slice(rth_builder* b, int list) { LST(list); return push_obj(b, b->lists[list].to_hittable_slice()); }
+int rth_slice(rth_builder* b, int list) { NEEDB; LST(list); GUARD(return push_obj(b, b->lists[list].to_hittable_slice());) }
 int rth_bvh(rth_builder* b, int list) {
-    LST(list);
+    NEEDB; LST(list);
     GUARD(return push_obj(b, b->lists[list].to_bvh_node());)
 }
 int rth_translate(rth_builder* b, int obj, const double* off) {
-    OBJ(obj);
-    return push_obj(b, std::make_shared<Translate>(b->objects[obj], p3(off)));
+    NEEDB; OBJ(obj);
+    if (!off) return bad(b, "null offset");
+    GUARD(return push_obj(b, std::make_shared<Translate>(b->objects[obj], p3(off)));)
 }
 int rth_rotate_y(rth_builder* b, int obj, double deg) {
-    OBJ(obj);
+    NEEDB; OBJ(obj);
     GUARD(return push_obj(b, std::make_shared<RotateY>(b->objects[obj], deg));)
 }
 int rth_constant_medium(rth_builder* b, int boundary, double density, int tex) {
-    OBJ(boundary); TEX(tex);
-    return push_obj(b, std::make_shared<ConstantMedium>(b->objects[boundary], density, b->textures[tex]));
+    NEEDB; OBJ(boundary); TEX(tex);
+    GUARD(return push_obj(b, std::make_shared<ConstantMedium>(b->objects[boundary], density, b->textures[tex]));)
 }
 int rth_load_model(rth_builder* b, const char* path, double scale, int mat) {
-    MAT(mat);
+    NEEDB; MAT(mat);
+    if (!path) return bad(b, "null path");
     GUARD(return push_obj(b, load_model(path, scale, b->materials[mat]));)
 }
 int rth_bbox(rth_builder* b, int obj, double* o) {
-    OBJ(obj);
+    NEEDB; OBJ(obj);
+    if (!o) return bad(b, "null output");
     const AABB& bb = b->objects[obj]->bounding_box();
     o[0] = bb.x.start; o[1] = bb.x.end; o[2] = bb.y.start; o[3] = bb.y.end; o[4] = bb.z.start; o[5] = bb.z.end;
     return 0;
 }
 int rth_extent(rth_builder* b, int obj, double* o) {
-    OBJ(obj);
+    NEEDB; OBJ(obj);
+    if (!o) return bad(b, "null output");
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     b->objects[obj]->extent(lo, hi);
     for (int c = 0; c < 3; ++c) { o[2 * c] = lo[c]; o[2 * c + 1] = hi[c]; }
     return 0;
 }
 int rth_set_world(rth_builder* b, int obj) {
-    OBJ(obj);
+    NEEDB; OBJ(obj);
     GUARD(
         b->flat = flatten(*b->objects[obj]);
         b->texels.clear(); b->image_desc.clear(); b->perlin_vec.clear(); b->perlin_perm.clear();
@@ -161,10 +175,10 @@ int rth_set_world(rth_builder* b, int obj) {
         b->have_flat = true;
         return 0;)
 }
-uint32_t rth_num_prim_ids(rth_builder* b) { return b->have_flat ? b->flat.n_prim_ids : 0; }
+uint32_t rth_num_prim_ids(rth_builder* b) { return (b && b->have_flat) ? b->flat.n_prim_ids : 0; }
 const void* rth_flat_array(rth_builder* b, int what, uint64_t* count) {
-    *count = 0;
-    if (!b->have_flat) return nullptr;
+    if (count) *count = 0;
+    if (!b || !count || !b->have_flat) return nullptr;
     const FlatScene& f = b->flat;
 #define RET(vec, per) { *count = (vec).size() / (per); return (vec).data(); }
     switch (what) {
@@ -197,17 +211,37 @@ const void* rth_flat_array(rth_builder* b, int what, uint64_t* count) {
 #undef RET
 }
 rt_scene* rth_commit(rth_builder* b, int device) {
+    if (!b) return nullptr;
     if (!b->have_flat) { b->err = "rth_set_world has not been called"; return nullptr; }
-    rt_scene* s = b->flat.commit(device);
-    if (!s) b->err = rt_last_error();
-    return s;
+    try {
+        rt_scene* s = b->flat.commit(device);
+        if (!s) b->err = rt_last_error();
+        return s;
+    } catch (const std::exception& e) {
+        b->err = e.what();
+    } catch (...) {
+        b->err = "unexpected failure";
+    }
+    return nullptr;
 }
 void rth_camera_new(double aspect_ratio, uint32_t image_width, double vfov, double defocus_angle, double focus_distance,
                     const double* look_from, const double* look_at, const double* view_up, rt_camera* out) {
-    Camera c = Camera::create(aspect_ratio, image_width, ImageQuality{1, 1}, vfov, ThinLens{defocus_angle, focus_distance},
-                              CameraPosition{p3(look_from), p3(look_at), p3(view_up)}, Color(0, 0, 0));
-    *out = c.cam;
+    if (!look_from || !look_at || !view_up || !out) return;
+    try {
+        Camera c = Camera::create(aspect_ratio, image_width, ImageQuality{1, 1}, vfov, ThinLens{defocus_angle, focus_distance},
+                                  CameraPosition{p3(look_from), p3(look_at), p3(view_up)}, Color(0, 0, 0));
+        *out = c.cam;
+    } catch (...) {
+        std::memset(out, 0, sizeof *out);  // (an image of width 0 is refused by every render call)
+    }
 }
-int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) { return write_png(path, rgb8, w, h) ? 0 : -1; }
+int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+    if (!path || !rgb8 || !w || !h) return -1;
+    try {
+        return write_png(path, rgb8, w, h) ? 0 : -1;
+    } catch (...) {
+        return -1;
+    }
+}
 
 }  // extern "C"

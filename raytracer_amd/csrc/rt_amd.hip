@@ -184,6 +184,7 @@ struct TravArgs {
     uint32_t resume;        // 1: go on from the closest hit in `hb` (what the stretches before this one have left)
     const uint32_t* wl;       // gated launch: the queue slots to work on and where their number is; null: every ray
     const uint32_t* wl_count;
+    int thr_fetch, thr_step;  // wide kernel: lanes that must be waiting before rays are handed out / a step is taken
 };
 __device__ __forceinline__ Best trav_best_setup(const TravArgs& a, uint32_t idx) {
     Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide
         const unsigned long long mask = __ballot(need);
         int n_node = __popcll(__ballot(ln.state == RT_W_NODE));
         int n_prim = __popcll(__ballot(ln.state == RT_W_PRIM));
-        if (mask != 0ull && (__popcll(mask) >= RT_WIDE_FETCH_THRESHOLD || n_node + n_prim == 0)) {
+        if (mask != 0ull && (__popcll(mask) >= a.thr_fetch || n_node + n_prim == 0)) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
             if (PROF) { pc[3]++; pc[6] += (unsigned long long)__popcll(mask); }
             if (need && idx != 0xFFFFFFFFu) {
@@ -392,8 +393,8 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide
             n_prim = __popcll(__ballot(ln.state == RT_W_PRIM));
             if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[0] += clock64() - t0; }
         }
-        const bool do_node = n_node >= RT_WIDE_STEP_THRESHOLD || n_node >= n_prim;
-        const bool do_prim = n_prim >= RT_WIDE_STEP_THRESHOLD || n_prim > n_node;
+        const bool do_node = n_node >= a.thr_step || n_node >= n_prim;
+        const bool do_prim = n_prim >= a.thr_step || n_prim > n_node;
         if (do_node) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
             if (ln.state == RT_W_NODE) wide_node_step(W, ln);
@@ -967,6 +968,8 @@ rt_scene* rt_scene_create(void) {
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->device >= 0) {
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         (void)hipSetDevice(s->device);
         free_list(s->allocs);
         free_list(s->ws_allocs);
@@ -975,6 +978,7 @@ void rt_scene_destroy(rt_scene* s) {
         for (auto& r : s->ring_ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
         if (s->h_ring) (void)hipHostFree(s->h_ring);
         if (s->stream) (void)hipStreamDestroy(s->stream);
+        if (prev >= 0) (void)hipSetDevice(prev);
     }
     delete s;
 }
@@ -983,19 +987,19 @@ void rt_scene_destroy(rt_scene* s) {
     if (!(s)) return fail(RT_ERR_INVALID, "null scene");                           \
     if ((s)->committed) return fail(RT_ERR_STATE, "scene already committed")
 
-int rt_scene_set_materials(rt_scene* s, const rt_material* m, uint32_t n) {
+static int rt_scene_set_materials_impl(rt_scene* s, const rt_material* m, uint32_t n) {
     NEED_UNCOMMITTED(s);
     if (n && !m) return fail(RT_ERR_INVALID, "null materials");
     s->mats.assign(m, m + n);
     return RT_OK;
 }
-int rt_scene_set_textures(rt_scene* s, const rt_texture* t, uint32_t n) {
+static int rt_scene_set_textures_impl(rt_scene* s, const rt_texture* t, uint32_t n) {
     NEED_UNCOMMITTED(s);
     if (n && !t) return fail(RT_ERR_INVALID, "null textures");
     s->texs.assign(t, t + n);
     return RT_OK;
 }
-int rt_scene_set_image(rt_scene* s, uint32_t slot, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+static int rt_scene_set_image_impl(rt_scene* s, uint32_t slot, const uint8_t* rgb8, uint32_t w, uint32_t h) {
     NEED_UNCOMMITTED(s);
     if (!rgb8 || !w || !h) return fail(RT_ERR_INVALID, "empty image");
     if (slot >= 4096) return fail(RT_ERR_LIMIT, "image slot %u too large", slot);
@@ -1006,7 +1010,7 @@ int rt_scene_set_image(rt_scene* s, uint32_t slot, const uint8_t* rgb8, uint32_t
     s->images[slot].set = true;
     return RT_OK;
 }
-int rt_scene_set_perlin(rt_scene* s, uint32_t slot, const double* vec256x3, const uint32_t* perm3x256) {
+static int rt_scene_set_perlin_impl(rt_scene* s, uint32_t slot, const double* vec256x3, const uint32_t* perm3x256) {
     NEED_UNCOMMITTED(s);
     if (!vec256x3 || !perm3x256) return fail(RT_ERR_INVALID, "null perlin tables");
     if (slot >= 4096) return fail(RT_ERR_LIMIT, "perlin slot %u too large", slot);
@@ -1028,29 +1032,29 @@ static int set_prims(rt_scene* s, std::vector<double>& dst, std::vector<uint32_t
     did.assign(id, id + n);
     return RT_OK;
 }
-int rt_scene_set_spheres(rt_scene* s, const double* cr, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+static int rt_scene_set_spheres_impl(rt_scene* s, const double* cr, const uint32_t* mat, const uint32_t* id, uint32_t n) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     return set_prims(s, s->spheres, s->sphere_mat, s->sphere_id, cr, 4, mat, id, n);
 }
-int rt_scene_set_quads(rt_scene* s, const double* rec16, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+static int rt_scene_set_quads_impl(rt_scene* s, const double* rec16, const uint32_t* mat, const uint32_t* id, uint32_t n) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     return set_prims(s, s->quads, s->quad_mat, s->quad_id, rec16, 16, mat, id, n);
 }
-int rt_scene_set_triangles(rt_scene* s, const double* rec16, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+static int rt_scene_set_triangles_impl(rt_scene* s, const double* rec16, const uint32_t* mat, const uint32_t* id, uint32_t n) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     return set_prims(s, s->tris, s->tri_mat, s->tri_id, rec16, 16, mat, id, n);
 }
-int rt_scene_set_quadrics(rt_scene* s, const double* rec10, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+static int rt_scene_set_quadrics_impl(rt_scene* s, const double* rec10, const uint32_t* mat, const uint32_t* id, uint32_t n) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     return set_prims(s, s->quadrics, s->quadric_mat, s->quadric_id, rec10, 10, mat, id, n);
 }
-int rt_scene_set_media(rt_scene* s, const rt_medium* m, uint32_t n) {
+static int rt_scene_set_media_impl(rt_scene* s, const rt_medium* m, uint32_t n) {
     NEED_UNCOMMITTED(s);
     if (n && !m) return fail(RT_ERR_INVALID, "null media");
     s->media.assign(m, m + n);
     return RT_OK;
 }
-int rt_scene_set_xforms(rt_scene* s, const rt_xform_op* ops, uint32_t n_ops, const rt_chain* chains,
+static int rt_scene_set_xforms_impl(rt_scene* s, const rt_xform_op* ops, uint32_t n_ops, const rt_chain* chains,
                         uint32_t n_chains) {
     NEED_UNCOMMITTED(s);
     if ((n_ops && !ops) || (n_chains && !chains)) return fail(RT_ERR_INVALID, "null transform arrays");
@@ -1059,14 +1063,14 @@ int rt_scene_set_xforms(rt_scene* s, const rt_xform_op* ops, uint32_t n_ops, con
     s->chains.assign(chains, chains + n_chains);
     return RT_OK;
 }
-int rt_scene_set_nodes(rt_scene* s, const rt_node* nodes, uint32_t n_nodes, const double* boxes6, uint32_t n_boxes) {
+static int rt_scene_set_nodes_impl(rt_scene* s, const rt_node* nodes, uint32_t n_nodes, const double* boxes6, uint32_t n_boxes) {
     NEED_UNCOMMITTED(s);
     if ((n_nodes && !nodes) || (n_boxes && !boxes6)) return fail(RT_ERR_INVALID, "null node arrays");
     s->nodes.assign(nodes, nodes + n_nodes);
     s->boxes.assign(boxes6, boxes6 + (size_t)6 * n_boxes);
     return RT_OK;
 }
-int rt_scene_set_cull_boxes(rt_scene* s, const double* tight6, uint32_t n_boxes) {
+static int rt_scene_set_cull_boxes_impl(rt_scene* s, const double* tight6, uint32_t n_boxes) {
     NEED_UNCOMMITTED(s);
     if (n_boxes && !tight6) return fail(RT_ERR_INVALID, "null cull boxes");
     s->cull_boxes.assign(tight6, tight6 + (size_t)6 * n_boxes);
@@ -1204,7 +1208,7 @@ static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
 }
 }  // extern "C++"
 
-int rt_scene_commit(rt_scene* s, int device) {
+static int rt_scene_commit_impl(rt_scene* s, int device) {
     NEED_UNCOMMITTED(s);
     int rc = validate(s);
     if (rc) return rc;
@@ -1400,6 +1404,9 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
             static const uint32_t wdiv = getenv("RT_WIDE_DIV") ? (uint32_t)atoi(getenv("RT_WIDE_DIV")) : 1u;
             const uint32_t grid = std::min(waves, s->wide_waves / wdiv);
             a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
+            static const int tf = getenv("RT_WIDE_TF") ? atoi(getenv("RT_WIDE_TF")) : RT_WIDE_FETCH_THRESHOLD;
+            static const int ts = getenv("RT_WIDE_TS") ? atoi(getenv("RT_WIDE_TS")) : RT_WIDE_STEP_THRESHOLD;
+            a.thr_fetch = tf; a.thr_step = ts;
             static const bool prof = getenv("RT_WIDE_PROF") != nullptr;
             if (prof) hipLaunchKernelGGL(k_traverse_wide<true>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3));
             else hipLaunchKernelGGL(k_traverse_wide<false>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4, nullptr);
@@ -1430,7 +1437,7 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
     return RT_OK;
 }
 
-int rt_intersect_batch(const rt_scene* s_, uint64_t seed, const double* o3, const double* d3, const double* tmin,
+static int rt_intersect_batch_impl(const rt_scene* s_, uint64_t seed, const double* o3, const double* d3, const double* tmin,
                        const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim, double* t,
                        double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out) {
     rt_scene* s = const_cast<rt_scene*>(s_);
@@ -1558,7 +1565,7 @@ static int check_render_args(const rt_scene* s, const rt_camera* cam, const rt_r
 // costs as much as its slowest ray).  A batch's radiances land in its own section of the luminance buffer and are
 // added to the film, batch after batch and sample after sample, once the batch is `max_depth` iterations old or
 // nothing is in flight: the film is the same in-order sum whatever the queue size.
-int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, void* film_dev,
+static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, void* film_dev,
                      rt_stats* stats) {
     rt_scene* s = const_cast<rt_scene*>(s_);
     NEED_COMMITTED(s);
@@ -1633,7 +1640,16 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
         st.rays = h[0];
         st.bounces = (uint32_t)h[1] + 1u;
     } else if (o->max_depth > 0 && o->spp_count > 0) {
-        const uint64_t want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (32ull << 20), npix);
+        // Paths in flight: 32 M by default; four times that for a tree with BVH entries, whose launches hand rays to
+        // resident wavefronts and end with a tail of few busy lanes (about 270 bytes of queues, hit buffers, work lists
+        // and radiance slots per path), and never more than a quarter of the device memory that is free.
+        uint64_t dflt = s->has_bvh ? (128ull << 20) : (32ull << 20);
+        if (!o->batch_paths) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && s->ws_paths == 0)
+                dflt = std::min<uint64_t>(dflt, std::max<uint64_t>(1ull << 20, (uint64_t)free_b / 4 / 270));
+        }
+        const uint64_t want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : dflt, npix);
         uint32_t spb = (uint32_t)std::max<uint64_t>(1, (want / 4) / npix);  // samples per batch
         spb = std::min(spb, o->spp_count);
         const uint64_t bsize = (uint64_t)spb * npix;                      // paths per full batch
@@ -1739,13 +1755,16 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
                 segs.nclass = nclass;
                 segs.stride = (uint32_t)qcap;
                 segs.fresh = fresh;
-                const uint32_t blocks = (upper_in + BOUNCE_BLOCK - 1) / BOUNCE_BLOCK + nclass + 1u;
+                // (a deep tree's interval slots for 256 lanes would not fit a workgroup's LDS; the kernel has no
+                // workgroup-wide step, so one wavefront per workgroup serves as well)
+                const uint32_t fblock = levels_lds(s, BOUNCE_BLOCK) > 48u * 1024u ? 64u : (uint32_t)BOUNCE_BLOCK;
+                const uint32_t blocks = (upper_in + fblock - 1) / fblock + nclass + 1u;
                 HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));
                 HIP_TRY(hipEventRecord(s->ev[1], sm));
 #define FINISH_ARGS d, o->seed, segs, qin, s->lum_r, s->lum_g, s->lum_b, o->background[0], o->background[1], \
                     o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8)
-#define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(BOUNCE_BLOCK), \
-                                            levels_lds(s, BOUNCE_BLOCK), sm, FINISH_ARGS)
+#define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(fblock), \
+                                            levels_lds(s, fblock), sm, FINISH_ARGS)
                 if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
                 else if (!lockstep) { if (s->plain) FINISH(false, RT_MEDIA_ANY, true); else FINISH(false, RT_MEDIA_ANY, false); }
                 else if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(true, RT_MEDIA_NONE, true); else FINISH(true, RT_MEDIA_NONE, false); }
@@ -1857,7 +1876,7 @@ int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     return RT_OK;
 }
 
-int rt_render(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, double* film_rgb, rt_stats* stats) {
+static int rt_render_impl(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, double* film_rgb, rt_stats* stats) {
     rt_scene* s = const_cast<rt_scene*>(s_);
     NEED_COMMITTED(s);
     int rc = check_render_args(s, cam, o);
@@ -1867,14 +1886,14 @@ int rt_render(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o,
     size_t bytes = (size_t)3 * cam->width * cam->height * sizeof(double);
     void* d_film = nullptr;
     HIP_TRY(hipMalloc(&d_film, bytes));
-    rc = rt_render_device(s, cam, o, d_film, stats);
+    rc = rt_render_device_impl(s, cam, o, d_film, stats);
     if (rc == RT_OK && hipMemcpy(film_rgb, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(RT_ERR_DEVICE, "film copy back failed");
     (void)hipFree(d_film);
     return rc;
 }
 
-int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* o,
+static int rt_render_multi_impl(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* o,
                     double* film_rgb, rt_stats* stats) {
     if (!scenes || n < 1 || n > 64) return fail(RT_ERR_INVALID, "bad scene list");
     for (int r = 0; r < n; ++r) {
@@ -1901,7 +1920,7 @@ int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, 
             hipError_t e = hipSetDevice(scenes[r]->device);
             if (e == hipSuccess) e = hipMalloc(&me.film, bytes);
             if (e != hipSuccess) { me.rc = RT_ERR_DEVICE; me.err = hipGetErrorString(e); return; }
-            me.rc = rt_render_device(scenes[r], cam, &mine, me.film, &me.st);
+            me.rc = rt_render_device_impl(scenes[r], cam, &mine, me.film, &me.st);
             if (me.rc != RT_OK) me.err = rt_last_error();  // the error text is per thread
         });
     }
@@ -1960,7 +1979,7 @@ int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, 
     return rc;
 }
 
-int rt_trace_samples(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, uint64_t n,
+static int rt_trace_samples_impl(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, uint64_t n,
                      const uint32_t* pixel, const uint32_t* sample, double* radiance3, uint32_t* nrays) {
     rt_scene* s = const_cast<rt_scene*>(s_);
     NEED_COMMITTED(s);
@@ -1995,7 +2014,7 @@ int rt_trace_samples(const rt_scene* s_, const rt_camera* cam, const rt_render_o
     return rc;
 }
 
-int rt_tonemap_rgb8(const rt_scene* s_, const double* film_rgb, uint32_t width, uint32_t height, uint32_t spp,
+static int rt_tonemap_rgb8_impl(const rt_scene* s_, const double* film_rgb, uint32_t width, uint32_t height, uint32_t spp,
                     uint8_t* rgb8) {
     rt_scene* s = const_cast<rt_scene*>(s_);
     NEED_COMMITTED(s);
@@ -2021,7 +2040,7 @@ int rt_tonemap_rgb8(const rt_scene* s_, const double* film_rgb, uint32_t width, 
     return rc;
 }
 
-int rt_debug_arith(int device, const double* a, const double* b, uint64_t n, double* quot, double* root, double* recip,
+static int rt_debug_arith_impl(int device, const double* a, const double* b, uint64_t n, double* quot, double* root, double* recip,
                    double* logv) {
     if (!a || !b || !quot || !root || !recip || !logv) return fail(RT_ERR_INVALID, "null arrays");
     if (n == 0) return RT_OK;
@@ -2049,6 +2068,90 @@ int rt_debug_arith(int device, const double* a, const double* b, uint64_t n, dou
     } while (0);
     free_list(tmp);
     return rc;
+}
+
+
+// ---- the exported entry points: no exception crosses the boundary, and the caller's current HIP device is the same
+// after a call as before it
+extern "C++" {
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+template <class F>
+static int guarded(F&& f) {
+    DeviceGuard keep;
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_LIMIT, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_INVALID, "unexpected failure: %s", e.what());
+    } catch (...) {
+        return fail(RT_ERR_INVALID, "unexpected failure");
+    }
+}
+}  // extern "C++"
+int rt_scene_set_materials(rt_scene* s, const rt_material* m, uint32_t n) {
+    return guarded([&]() -> int { return rt_scene_set_materials_impl(s, m, n); });
+}
+int rt_scene_set_textures(rt_scene* s, const rt_texture* t, uint32_t n) {
+    return guarded([&]() -> int { return rt_scene_set_textures_impl(s, t, n); });
+}
+int rt_scene_set_image(rt_scene* s, uint32_t slot, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+    return guarded([&]() -> int { return rt_scene_set_image_impl(s, slot, rgb8, w, h); });
+}
+int rt_scene_set_perlin(rt_scene* s, uint32_t slot, const double* vec256x3, const uint32_t* perm3x256) {
+    return guarded([&]() -> int { return rt_scene_set_perlin_impl(s, slot, vec256x3, perm3x256); });
+}
+int rt_scene_set_spheres(rt_scene* s, const double* cr, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+    return guarded([&]() -> int { return rt_scene_set_spheres_impl(s, cr, mat, id, n); });
+}
+int rt_scene_set_quads(rt_scene* s, const double* rec16, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+    return guarded([&]() -> int { return rt_scene_set_quads_impl(s, rec16, mat, id, n); });
+}
+int rt_scene_set_triangles(rt_scene* s, const double* rec16, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+    return guarded([&]() -> int { return rt_scene_set_triangles_impl(s, rec16, mat, id, n); });
+}
+int rt_scene_set_quadrics(rt_scene* s, const double* rec10, const uint32_t* mat, const uint32_t* id, uint32_t n) {
+    return guarded([&]() -> int { return rt_scene_set_quadrics_impl(s, rec10, mat, id, n); });
+}
+int rt_scene_set_media(rt_scene* s, const rt_medium* m, uint32_t n) {
+    return guarded([&]() -> int { return rt_scene_set_media_impl(s, m, n); });
+}
+int rt_scene_set_xforms(rt_scene* s, const rt_xform_op* ops, uint32_t n_ops, const rt_chain* chains, uint32_t n_chains) {
+    return guarded([&]() -> int { return rt_scene_set_xforms_impl(s, ops, n_ops, chains, n_chains); });
+}
+int rt_scene_set_nodes(rt_scene* s, const rt_node* nodes, uint32_t n_nodes, const double* boxes6, uint32_t n_boxes) {
+    return guarded([&]() -> int { return rt_scene_set_nodes_impl(s, nodes, n_nodes, boxes6, n_boxes); });
+}
+int rt_scene_set_cull_boxes(rt_scene* s, const double* tight6, uint32_t n_boxes) {
+    return guarded([&]() -> int { return rt_scene_set_cull_boxes_impl(s, tight6, n_boxes); });
+}
+int rt_scene_commit(rt_scene* s, int device) {
+    return guarded([&]() -> int { return rt_scene_commit_impl(s, device); });
+}
+int rt_intersect_batch(const rt_scene* s_, uint64_t seed, const double* o3, const double* d3, const double* tmin, const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim, double* t, double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out) {
+    return guarded([&]() -> int { return rt_intersect_batch_impl(s_, seed, o3, d3, tmin, tmax, rng3, n, hit, prim, t, p3, n3, uv2, front, ctr_out); });
+}
+int rt_render_device(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, void* film_dev, rt_stats* stats) {
+    return guarded([&]() -> int { return rt_render_device_impl(s_, cam, o, film_dev, stats); });
+}
+int rt_render(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, double* film_rgb, rt_stats* stats) {
+    return guarded([&]() -> int { return rt_render_impl(s_, cam, o, film_rgb, stats); });
+}
+int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* o, double* film_rgb, rt_stats* stats) {
+    return guarded([&]() -> int { return rt_render_multi_impl(scenes, n, cam, o, film_rgb, stats); });
+}
+int rt_trace_samples(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, uint64_t n, const uint32_t* pixel, const uint32_t* sample, double* radiance3, uint32_t* nrays) {
+    return guarded([&]() -> int { return rt_trace_samples_impl(s_, cam, o, n, pixel, sample, radiance3, nrays); });
+}
+int rt_tonemap_rgb8(const rt_scene* s_, const double* film_rgb, uint32_t width, uint32_t height, uint32_t spp, uint8_t* rgb8) {
+    return guarded([&]() -> int { return rt_tonemap_rgb8_impl(s_, film_rgb, width, height, spp, rgb8); });
+}
+int rt_debug_arith(int device, const double* a, const double* b, uint64_t n, double* quot, double* root, double* recip, double* logv) {
+    return guarded([&]() -> int { return rt_debug_arith_impl(device, a, b, n, quot, root, recip, logv); });
 }
 
 }  // extern "C"

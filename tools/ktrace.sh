@@ -3,7 +3,7 @@
 tag=$1; cfg=$2; spp=$3
 root=$(pwd); out=$root/gpurun_out/kt_$tag; mkdir -p $out
 export TMPDIR=/tmp; cd /tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --config $cfg --spp $spp --steps 1 --warmup 0 --no-cpu-baseline > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --config $cfg --spp $spp --steps 1 --warmup 0 --no-cpu-baseline --no-also > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 cd $root
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY' | tee $out/stats.txt

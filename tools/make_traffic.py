@@ -1,38 +1,68 @@
 #!/usr/bin/env python3
-"""Writes profiles/traffic.json (read by bench.py for roofline.traffic) from the PMC summaries under profiles/.
+"""Writes profiles/traffic.json (read by bench.py for roofline.traffic / roofline_hbm and the VALU issue account) from
+the PMC summaries tools/profile.sh leaves under gpurun_out/prof_<tag>/ (copied to profiles/).
 
-HBM bytes per launch of a kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / dispatches: rocprofv3 reports both counters
-in KiB, and on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so the read side is doubled.  The two
-counters come from separate --pmc passes of the same command (tools/profile.sh).
+Per workload, for the dominant kernel bench.py names (for trees with BVH entries: all launches of a bounce's traverse
+phase together):
+  hbm_bytes_per_ray = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / rays of the profiled run's timed steps.  rocprofv3 reports
+      both counters in KiB, and on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so the read side is
+      doubled.  The two counters come from separate --pmc passes of the same command.
+  valu_issue: SQ_INSTS_VALU x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz x the kernel's summed duration): the share of
+      the SIMDs' issue slots the kernel's vector instructions take ("VALU busy"), with the numbers it is made of;
+      lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU).
 
-usage: tools/make_traffic.py <config>=<summary.json> [...]"""
+usage: tools/make_traffic.py <config>=<summary.json>,<bench.json> [...]   (bench.json: the line bench.py printed in
+the kernel-trace pass of that profile)"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRAVERSE = ("k_traverse_lockstep", "k_traverse_wide", "k_traverse_persistent")
 
 
 def main():
+    path_out = os.path.join(ROOT, "profiles", "traffic.json")
     out = {}
+    if os.path.exists(path_out):
+        with open(path_out) as fh:
+            out = json.load(fh)
     for arg in sys.argv[1:]:
-        cfg, path = arg.split("=", 1)
-        with open(path) as fh:
+        cfg, paths = arg.split("=", 1)
+        summary, bench = paths.split(",")
+        with open(summary) as fh:
             kernels = json.load(fh)["kernels"]
-        entry = {}
+        with open(bench) as fh:
+            line = json.loads([l for l in fh if '"metric"' in l][-1])
+        roof = line["roofline"]
+        wanted = TRAVERSE if roof["kernel"].startswith("traverse phase") else (roof["kernel"].split(" ")[0],)
+        agg = {}
+        ms = 0.0
+        names = []
         for name, k in kernels.items():
-            c = k["counters"]
-            if not k["dispatches"] or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-                continue
             base = name.split("<")[0]
-            # the traverse / whole-path instantiations whose first template argument (COUNT) is true only run in the
-            # untimed counting passes
-            if base != "k_shade" and "<true" in name:
+            # instantiations whose first template argument (COUNT) is true only run in the untimed counting passes
+            if base not in wanted or (base != "k_traverse_wide" and "<true" in name) or not k["dispatches"]:
                 continue
-            entry[base + "_hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / k["dispatches"]
-            entry[base + "_avg_ms"] = k["avg_ms"]
+            names.append(name)
+            ms += k["total_ms"]
+            for c, v in k["counters"].items():
+                agg[c] = agg.get(c, 0.0) + v
+        if not names or "FETCH_SIZE" not in agg:
+            print(f"{cfg}: no counters for {wanted}", file=sys.stderr)
+            continue
+        rays = roof["rays_per_launch"] * roof["launches"]
+        entry = {"kernel": roof["kernel"], "profiled_kernels": sorted(names), "profiled_rays": rays, "profiled_kernel_ms": ms,
+                 "hbm_bytes_per_ray": (2.0 * agg["FETCH_SIZE"] + agg["WRITE_SIZE"]) * 1024.0 / rays,
+                 "source": os.path.relpath(summary, ROOT)}
+        if "SQ_INSTS_VALU" in agg:
+            entry["valu_issue"] = {
+                "valu_insts": agg["SQ_INSTS_VALU"], "waves": agg.get("SQ_WAVES"), "cycles_per_inst": 4, "simds": 1024,
+                "clock_ghz": 2.4, "kernel_ms": ms, "frac": agg["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * ms * 1e-3),
+                "lanes_active": agg["SQ_THREAD_CYCLES_VALU"] / (64.0 * agg["SQ_ACTIVE_INST_VALU"]) if agg.get("SQ_ACTIVE_INST_VALU") else None,
+                "valu_insts_per_ray": agg["SQ_INSTS_VALU"] / rays}
         out[cfg] = entry
-    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fh:
+    with open(path_out, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 

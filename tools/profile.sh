@@ -6,7 +6,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="python3 $root/bench.py --config $cfg --spp $spp --steps ${STEPS:-1} --warmup ${WARMUP:-0} --no-cpu-baseline"
+cmd="python3 $root/bench.py --config $cfg --spp $spp --steps ${STEPS:-1} --warmup ${WARMUP:-0} --no-cpu-baseline --no-also"
 cd /tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $cmd > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 i=0
@@ -20,6 +20,7 @@ for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_R
 done
 cd $root
 python3 tools/pmc_summary.py $out/trace $out/pmc* > $out/summary.json
+grep '"metric"' $out/trace.log | tail -1 > $out/bench.json
 find $out -name "*_kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 rm -rf $out/trace $out/pmc?  # keep only the summaries (raw CSVs are large)
 python3 - <<PY
