@@ -227,6 +227,25 @@ int rt_intersect_batch(const rt_scene* s, uint64_t seed, const double* o3, const
                        const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim,
                        double* t, double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out);
 
+/* The same for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Every pointer is DEVICE memory on the scene's
+ * device, owned by the caller; the call allocates nothing, on the device or through any library: what its kernels
+ * need beyond these arrays (the closest hits travelling between launches, a work counter) lives in a static device
+ * array of the library, 1 MiB + 256 bytes per GPU, held until the process ends.  Hence the limit: n <= 65536 rays per
+ * call (RT_ERR_LIMIT beyond it); and calls that overlap in time on one GPU -- from any thread, on any scene handle --
+ * share that array and race: issue them one after the other.
+ *   od6_dev    6 * n f64: all origin x, then origin y, origin z, direction x, y, z (structure of arrays)
+ *   tmin_dev, tmax_dev   n f64 each
+ *   rng3_dev   3 * n u32: all pixels, then all samples, then all first draw indices; the draw indices are updated
+ *              in place to the index after the last draw a ConstantMedium made (rt_intersect_batch's ctr_out)
+ *   outputs    as rt_intersect_batch's, in device memory; any of them may be NULL
+ * Results are those of rt_intersect_batch bit for bit.  The scene's stream is synchronised before the call returns. */
+#define RT_NOALLOC_MAX_RAYS 65536u
+int rt_intersect_batch_noalloc(const rt_scene* s, uint64_t seed, const double* od6_dev, const double* tmin_dev,
+                               const double* tmax_dev, uint32_t* rng3_dev, uint32_t n, uint8_t* hit_dev,
+                               uint32_t* prim_dev, double* t_dev, double* p3_dev, double* n3_dev, double* uv2_dev,
+                               uint8_t* front_dev);
+
 /* ---- Camera::render / thrender (camera.rs:217-271) -----------------------------------------------------
  * Renders samples [spp_begin, spp_begin + spp_count) of every pixel and writes film_rgb[3*(j*width+i)..] = the
  * SUM of their radiances (not the average), in sample order, so that shards rendered on different GPUs add up

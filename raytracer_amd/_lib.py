@@ -72,7 +72,7 @@ RT_AMD_SYMBOLS = [
     "rt_scene_set_image", "rt_scene_set_perlin", "rt_scene_set_spheres", "rt_scene_set_quads",
     "rt_scene_set_triangles", "rt_scene_set_quadrics", "rt_scene_set_media", "rt_scene_set_xforms",
     "rt_scene_set_nodes", "rt_scene_set_cull_boxes", "rt_scene_commit", "rt_intersect_batch", "rt_render", "rt_render_device",
-    "rt_render_multi", "rt_trace_samples", "rt_tonemap_rgb8", "rt_debug_arith",
+    "rt_render_multi", "rt_trace_samples", "rt_tonemap_rgb8", "rt_debug_arith", "rt_intersect_batch_noalloc",
 ]
 
 _amd = None
@@ -111,6 +111,7 @@ def amd():
     L.rt_scene_set_cull_boxes.argtypes = [vp, vp, u32]
     L.rt_scene_commit.argtypes = [vp, i32]
     L.rt_intersect_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rt_intersect_batch_noalloc.argtypes = [vp, u64, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), vp, C.POINTER(rt_stats)]
     L.rt_render_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), vp, C.POINTER(rt_stats)]
     L.rt_render_multi.argtypes = [vp, i32, C.POINTER(rt_camera), C.POINTER(rt_render_opts), vp, C.POINTER(rt_stats)]

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <numeric>
@@ -890,6 +891,27 @@ __global__ void k_debug_arith(const double* a, const double* b, uint64_t n, doub
     logv[i] = log(a[i]);
 }
 
+// ------------------------------------------------------------------------------------------------ static scratch
+// Device memory of rt_intersect_batch_noalloc, the entry point for callers that cannot allocate: the closest hits
+// that travel from one traverse launch to the next and on to the kernel that writes the records (8 + 4 + 4 bytes per
+// ray), then the counter the per-lane kernels hand rays out with.  One copy per GPU, held until the process ends.
+#define RT_SCRATCH_BYTES (RT_NOALLOC_MAX_RAYS * 16u + 256u)
+static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
+// The array's address on each device (the name above is only a host-side stand-in for it), looked up once per device
+// when a scene is first committed there.
+#define RT_MAX_DEVICES 64
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+static int scratch_lookup(int device) {  // with `device` current
+    if (device < 0 || device >= RT_MAX_DEVICES) return RT_OK;  // (such a device simply has no allocation-free entry point)
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return RT_OK;
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = static_cast<unsigned char*>(ptr);
+    return RT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ scene object
 struct DevBuf {
     void* p = nullptr;
@@ -1216,6 +1238,7 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(RT_ERR_DEVICE, "device %d not present (%d visible)", device, ndev);
     HIP_TRY(hipSetDevice(device));
+    if ((rc = scratch_lookup(device))) return rc;
     s->device = device;
     DScene& d = s->d;
     d.n_nodes = (uint32_t)s->nodes.size();
@@ -1384,7 +1407,8 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 
 // One traverse+intersect launch over the rays of `a` on the scene's stream.
 // `n_upper`: no fewer rays than the launch will find (it sizes the grid; the kernels read the true numbers themselves).
-static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool nocull, uint32_t n_upper) {
+static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool nocull, uint32_t n_upper, uint32_t* work = nullptr) {
+    if (!work) work = s->d_count + 4;  // the counter the per-lane kernels hand rays out with
     const size_t lds = levels_lds(s, TRAV_BLOCK);
     DScene d = s->d;
     if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
@@ -1400,7 +1424,7 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
                 a.wl = a_.wl + (size_t)st.wide * s->ws_paths;
                 a.wl_count = a_.wl_count + RT_COUNT_STRIDE * (4u + (uint32_t)st.wide);
             }
-            HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
+            HIP_TRY(hipMemsetAsync(work, 0, 4, s->stream));  // the work counter of this launch
             static const uint32_t wdiv = getenv("RT_WIDE_DIV") ? (uint32_t)atoi(getenv("RT_WIDE_DIV")) : 1u;
             const uint32_t grid = std::min(waves, s->wide_waves / wdiv);
             a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
@@ -1408,8 +1432,8 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
             static const int ts = getenv("RT_WIDE_TS") ? atoi(getenv("RT_WIDE_TS")) : RT_WIDE_STEP_THRESHOLD;
             a.thr_fetch = tf; a.thr_step = ts;
             static const bool prof = getenv("RT_WIDE_PROF") != nullptr;
-            if (prof) hipLaunchKernelGGL(k_traverse_wide<true>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3));
-            else hipLaunchKernelGGL(k_traverse_wide<false>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, s->d_count + 4, nullptr);
+            if (prof) hipLaunchKernelGGL(k_traverse_wide<true>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, work, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3));
+            else hipLaunchKernelGGL(k_traverse_wide<false>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, work, nullptr);
         } else if (st.kind == RT_STRETCH_LOCKSTEP) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
             if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
@@ -1418,14 +1442,14 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
             else LOCKSTEP(false, RT_MEDIA_ANY);
 #undef LOCKSTEP
         } else {
-            HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, s->stream));  // the work counter of this launch
+            HIP_TRY(hipMemsetAsync(work, 0, 4, s->stream));  // the work counter of this launch
             const uint32_t grid = std::min(waves, s->persist_waves);
             // RT_CHUNK rays per hand-out when there is plenty of work; fewer (down to one wavefront's worth) when the
             // launch is small, so that the rays spread over the whole device instead of queueing up behind a few waves
             a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->persist_waves) + 63u) / 64u * 64u));
             DScene dp = d;
             dp.n_nodes = st.end;  // where the per-lane walk stops
-#define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, dp, a, s->d_count + 4, s->d_tallies)
+#define PERSIST(C, M) hipLaunchKernelGGL((k_traverse_persistent<C, M>), dim3(grid), dim3(TRAV_BLOCK), lds, s->stream, dp, a, work, s->d_tallies)
             if (count) PERSIST(true, RT_MEDIA_ANY);
             else if (s->media_mode == RT_MEDIA_NONE) PERSIST(false, RT_MEDIA_NONE);
             else if (s->media_mode == RT_MEDIA_FLAT) PERSIST(false, RT_MEDIA_FLAT);
@@ -1501,6 +1525,44 @@ static int rt_intersect_batch_impl(const rt_scene* s_, uint64_t seed, const doub
     } while (0);
     free_list(tmp);
     return rc;
+}
+
+// rt_intersect_batch for callers that cannot allocate: rays and results stay in the caller's device memory, and the
+// only device memory the kernels use beyond them is the static array above.
+static int rt_intersect_batch_noalloc_impl(const rt_scene* s_, uint64_t seed, const double* od6, const double* tmin,
+                                           const double* tmax, uint32_t* rng3, uint32_t n, uint8_t* hit, uint32_t* prim,
+                                           double* t, double* p3, double* n3, double* uv2, uint8_t* front) {
+    rt_scene* s = const_cast<rt_scene*>(s_);
+    NEED_COMMITTED(s);
+    if (n == 0) return RT_OK;
+    if (n > RT_NOALLOC_MAX_RAYS)
+        return fail(RT_ERR_LIMIT, "rt_intersect_batch_noalloc takes at most %u rays per call (%u given): its scratch memory is a static array",
+                    RT_NOALLOC_MAX_RAYS, n);
+    if (!od6 || !tmin || !tmax || !rng3) return fail(RT_ERR_INVALID, "null ray arrays");
+    if (s->device < 0 || s->device >= RT_MAX_DEVICES || !g_scratch_ptr[s->device])
+        return fail(RT_ERR_STATE, "no static scratch memory on device %d", s->device);
+    HIP_TRY(hipSetDevice(s->device));
+    unsigned char* const base = g_scratch_ptr[s->device];  // this device's copy of the array
+    TravArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.q.ox = const_cast<double*>(od6); a.q.oy = a.q.ox + n; a.q.oz = a.q.ox + 2 * (size_t)n;
+    a.q.dx = a.q.ox + 3 * (size_t)n; a.q.dy = a.q.ox + 4 * (size_t)n; a.q.dz = a.q.ox + 5 * (size_t)n;
+    a.q.pix = rng3; a.q.smp = rng3 + n; a.q.ctr = rng3 + 2 * (size_t)n;
+    a.hb.t = reinterpret_cast<double*>(base);
+    a.hb.ref = reinterpret_cast<uint32_t*>(base + 8 * (size_t)RT_NOALLOC_MAX_RAYS);
+    a.hb.chain = reinterpret_cast<uint32_t*>(base + 12 * (size_t)RT_NOALLOC_MAX_RAYS);
+    uint32_t* const work = reinterpret_cast<uint32_t*>(base + 16 * (size_t)RT_NOALLOC_MAX_RAYS);
+    a.seed = seed;
+    a.segs.n = n;
+    a.segs.nclass = 1u;
+    a.tmin = tmin; a.tmax = tmax;
+    int rc = launch_traverse(s, a, false, false, n, work);  // (clears the counter before every launch that uses it)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_finalize_batch, dim3((n + 255u) / 256u), dim3(256), 0, s->stream, s->d, a.q, a.hb, n, hit, prim, t, p3,
+                       n3, uv2, front, (uint32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return RT_OK;
 }
 
 static int ws_queue(rt_scene* s, Queue& q, size_t n) {
@@ -2152,6 +2214,15 @@ int rt_tonemap_rgb8(const rt_scene* s_, const double* film_rgb, uint32_t width, 
 }
 int rt_debug_arith(int device, const double* a, const double* b, uint64_t n, double* quot, double* root, double* recip, double* logv) {
     return guarded([&]() -> int { return rt_debug_arith_impl(device, a, b, n, quot, root, recip, logv); });
+}
+
+int rt_intersect_batch_noalloc(const rt_scene* s, uint64_t seed, const double* od6_dev, const double* tmin_dev,
+                               const double* tmax_dev, uint32_t* rng3_dev, uint32_t n, uint8_t* hit_dev, uint32_t* prim_dev,
+                               double* t_dev, double* p3_dev, double* n3_dev, double* uv2_dev, uint8_t* front_dev) {
+    // (no exception guard: nothing in this path allocates, on the host or on the device)
+    DeviceGuard keep;
+    return rt_intersect_batch_noalloc_impl(s, seed, od6_dev, tmin_dev, tmax_dev, rng3_dev, n, hit_dev, prim_dev, t_dev, p3_dev,
+                                           n3_dev, uv2_dev, front_dev);
 }
 
 }  // extern "C"
