@@ -71,6 +71,16 @@ rt_scene* rth_commit(rth_builder* b, int device);
 void rth_camera_new(double aspect_ratio, uint32_t image_width, double vfov, double defocus_angle,
                     double focus_distance, const double* look_from, const double* look_at, const double* view_up,
                     rt_camera* out);
+/* Camera::thrender (camera.rs:248-271) with a camera already derived: flattens the tree under `world`, renders `spp`
+ * samples per pixel on GPU `device` and writes the tone-mapped image as PNG to output_path (the reference's is the
+ * fixed "images/image.png", whose directory must exist).  print_metrics != 0 prints one JSON line of what was traced
+ * to stdout, where the reference prints banners and a progress bar.  stats may be NULL. */
+int rth_thrender(rth_builder* b, int world, const rt_camera* cam, uint32_t spp, uint32_t max_depth,
+                 const double* background, uint64_t seed, int device, const char* output_path, int print_metrics,
+                 rt_stats* stats);
+/* The decoder behind ImageTexture::new_or_fallback (texture.rs:89-93): binary PPM or PNG -> RGB8, top row first.
+ * rgb8 may be NULL to ask for the size only; -1 when the file is neither or rgb8 is too small. */
+int rth_read_image(const char* path, uint8_t* rgb8, uint64_t capacity, uint32_t* w, uint32_t* h);
 int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h);
 
 #ifdef __cplusplus

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
 #include <memory>
 #include <string>
 #include <vector>
@@ -65,8 +66,8 @@ class ImageTexture : public Texture {
 public:
     std::vector<uint8_t> rgb;  // row-major RGB8, top row first
     uint32_t width = 0, height = 0;
-    // Reads a binary PPM (P6, maxval 255).  On failure returns the reference's magenta checker
-    // (ImageTexture::new_or_fallback, texture.rs:89-113).  JPEG/PNG decoding is not built in.
+    // Reads a binary PPM (P6, maxval 255) or a PNG.  On failure returns the reference's magenta checker
+    // (ImageTexture::new_or_fallback, texture.rs:89-113).  Binary PPM and PNG are decoded; JPEG is not.
     static TexturePtr new_or_fallback(const std::string& path);
     static std::shared_ptr<ImageTexture> from_rgb8(const uint8_t* rgb, uint32_t w, uint32_t h);
     rt_texture_kind kind() const override { return RT_TEX_IMAGE; }
@@ -287,6 +288,8 @@ public:
     uint64_t seed = 42;  // key of the counter-based generator (the reference is OS-seeded)
     int device = 0;
     std::string output_path = "images/image.png";  // camera.rs:238,270
+    FILE* metrics = nullptr;  // where render() prints one JSON line of what it traced (the reference prints banners and
+                              // a progress bar, camera.rs:252,256,269); null: nothing
     static Camera create(double aspect_ratio, uint32_t image_width, ImageQuality q, double vfov, ThinLens lens,
                          CameraPosition pos, Color background);  // Camera::new, camera.rs:80-143
     // Camera::render / Camera::thrender (camera.rs:217-271) on the GPU.  Returns 0, or an RT_ERR_* code.
@@ -294,6 +297,9 @@ public:
     int thrender(const Hittable& world, rt_stats* stats = nullptr) const { return render(world, stats); }
 };
 
+// Reads a binary PPM (P6) or a PNG into 8-bit RGB, top row first.  False when the file is neither (JPEG: convert it
+// beforehand; decoders differ in the last bit anyway).
+bool read_image_rgb8(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h);
 // Writes an 8-bit RGB PNG (zlib deflate).  Returns false on I/O failure.
 bool write_png(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h);
 

@@ -190,6 +190,12 @@ class OracleBuilder:
     def slice(self, lst):
         return self._ck(self.L.orc_slice(self.s, lst))
 
+    def slice_of(self, objects):
+        lst = self.list_new()
+        for o in objects:
+            self.list_add(lst, o)
+        return self.slice(lst)
+
     def bvh(self, lst):
         return self._ck(self.L.orc_bvh(self.s, lst))
 

@@ -164,6 +164,10 @@ def host():
     H.rth_commit.argtypes = [vp, i32]
     H.rth_camera_new.restype = None
     H.rth_camera_new.argtypes = [dbl, u32, dbl, dbl, dbl, vp, vp, vp, C.POINTER(rt_camera)]
+    H.rth_thrender.restype = i32
+    H.rth_thrender.argtypes = [vp, i32, C.POINTER(rt_camera), u32, u32, vp, C.c_uint64, i32, cp, i32, C.POINTER(rt_stats)]
+    H.rth_read_image.restype = i32
+    H.rth_read_image.argtypes = [cp, vp, C.c_uint64, C.POINTER(u32), C.POINTER(u32)]
     H.rth_write_png.restype = i32
     H.rth_write_png.argtypes = [cp, vp, u32, u32]
     _host = H

@@ -104,6 +104,13 @@ class HostBuilder:
     def slice(self, lst):
         return self._ck(self.H.rth_slice(self.b, lst))
 
+    def slice_of(self, objects):
+        """to_hittable_slice of a fresh list holding `objects` in order."""
+        lst = self.list_new()
+        for o in objects:
+            self.list_add(lst, o)
+        return self.slice(lst)
+
     def bvh(self, lst):
         return self._ck(self.H.rth_bvh(self.b, lst))
 
@@ -132,6 +139,7 @@ class HostBuilder:
 
     def set_world(self, obj):
         self._ck(self.H.rth_set_world(self.b, obj))
+        self.world = obj
 
     # flattened view
     def num_prims(self):
@@ -172,6 +180,13 @@ class HostBuilder:
             out.append(rec)
         return out
 
+    def thrender(self, world, cam, spp, max_depth, background, output_path, seed=42, device=0, print_metrics=False):
+        """Camera::thrender of the host layer: renders the tree under `world` on the GPU and writes the PNG."""
+        st = _lib.rt_stats()
+        self._ck(self.H.rth_thrender(self.b, world, C.byref(cam), spp, max_depth, _d3(background), seed, device,
+                                     str(output_path).encode(), 1 if print_metrics else 0, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _lib.rt_stats._fields_}
+
     def commit(self, device=0):
         """Uploads the flattened world to a GPU and returns a Scene."""
         from .scene import Scene
@@ -187,6 +202,18 @@ def camera_new(aspect_ratio, image_width, vfov, defocus_angle, focus_distance, l
     _lib.host().rth_camera_new(aspect_ratio, image_width, vfov, defocus_angle, focus_distance, _d3(look_from),
                                _d3(look_at), _d3(view_up), C.byref(cam))
     return cam
+
+
+def read_image(path):
+    """The decoder behind ImageTexture::new_or_fallback: binary PPM or PNG -> (H, W, 3) uint8, or None."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    H = _lib.host()
+    if H.rth_read_image(str(path).encode(), None, 0, C.byref(w), C.byref(h)) != 0:
+        return None
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    if H.rth_read_image(str(path).encode(), out.ctypes.data, out.size, C.byref(w), C.byref(h)) != 0:
+        return None
+    return out
 
 
 def write_png(path, rgb):

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <limits>
 #include <map>
 #include <sstream>
@@ -124,10 +125,109 @@ static bool read_ppm(const std::string& path, std::vector<uint8_t>& rgb, uint32_
     h = (uint32_t)H;
     return true;
 }
+// PNG (the reference decodes through the `image` crate, texture.rs:90-93): 8- and 16-bit grey, grey + alpha, RGB,
+// RGBA and palette images, filters 0..4; interlaced files are refused.  Alpha is dropped and 16-bit samples keep their
+// high byte, which is what `image`'s to_rgb8() of such a file yields up to rounding.
+static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+static bool read_png(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (file.size() < 8 + 25 || std::memcmp(file.data(), sig, 8) != 0) return false;
+    std::vector<uint8_t> idat, palette;
+    uint32_t W = 0, H = 0, depth = 0, ctype = 0;
+    bool have_ihdr = false, done = false;
+    for (size_t at = 8; at + 12 <= file.size() && !done;) {
+        const uint32_t len = rd32(&file[at]);
+        if (len > file.size() || at + 12 + (size_t)len > file.size()) return false;
+        const uint8_t* tag = &file[at + 4];
+        const uint8_t* data = &file[at + 8];
+        if ((uint32_t)crc32(0L, tag, (uInt)(len + 4)) != rd32(data + len)) return false;
+        if (!std::memcmp(tag, "IHDR", 4)) {
+            if (len != 13) return false;
+            W = rd32(data); H = rd32(data + 4); depth = data[8]; ctype = data[9];
+            if (data[10] != 0 || data[11] != 0 || data[12] != 0) return false;  // compression, filter method, interlace
+            have_ihdr = true;
+        } else if (!std::memcmp(tag, "PLTE", 4)) {
+            palette.assign(data, data + len);
+        } else if (!std::memcmp(tag, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(tag, "IEND", 4)) {
+            done = true;
+        }
+        at += 12 + (size_t)len;
+    }
+    if (!have_ihdr || !done || W == 0 || H == 0 || W > 65536 || H > 65536) return false;
+    uint32_t channels;
+    switch (ctype) {
+        case 0: channels = 1; break;
+        case 2: channels = 3; break;
+        case 3: channels = 1; break;
+        case 4: channels = 2; break;
+        case 6: channels = 4; break;
+        default: return false;
+    }
+    if (ctype == 3 ? (depth != 1 && depth != 2 && depth != 4 && depth != 8)
+                   : (depth != 8 && depth != 16 && !(ctype == 0 && (depth == 1 || depth == 2 || depth == 4)))) return false;
+    if (ctype == 3 && (palette.empty() || palette.size() % 3 != 0)) return false;
+    const size_t bits_per_pixel = (size_t)channels * depth;
+    const size_t bpp = std::max<size_t>(1, bits_per_pixel / 8);      // the filters' byte distance
+    const size_t stride = ((size_t)W * bits_per_pixel + 7) / 8;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)H);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return false;
+    std::vector<uint8_t> prev(stride, 0), line(stride);
+    rgb.assign((size_t)3 * W * H, 0);
+    for (uint32_t y = 0; y < H; ++y) {
+        const uint8_t* in = &raw[(stride + 1) * (size_t)y];
+        const uint8_t ft = in[0];
+        if (ft > 4) return false;
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? line[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) / 2;
+            else if (ft == 4) {
+                const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            line[i] = (uint8_t)(in[1 + i] + pred);
+        }
+        uint8_t* out = &rgb[(size_t)3 * W * y];
+        for (uint32_t x = 0; x < W; ++x) {
+            auto sample = [&](uint32_t ch) -> uint32_t {  // channel ch of pixel x, as stored
+                if (depth == 8) return line[(size_t)x * channels + ch];
+                if (depth == 16) return line[((size_t)x * channels + ch) * 2];  // high byte
+                const size_t bit = (size_t)x * depth;                           // 1, 2, 4 bits: one channel
+                return (line[bit / 8] >> (8 - depth - bit % 8)) & ((1u << depth) - 1u);
+            };
+            if (ctype == 3) {
+                const uint32_t idx = sample(0);
+                if ((size_t)3 * idx + 2 >= palette.size()) return false;
+                out[3 * x] = palette[3 * idx]; out[3 * x + 1] = palette[3 * idx + 1]; out[3 * x + 2] = palette[3 * idx + 2];
+            } else if (ctype == 0 || ctype == 4) {
+                uint32_t v = sample(0);
+                if (depth < 8) v = v * 255u / ((1u << depth) - 1u);
+                out[3 * x] = out[3 * x + 1] = out[3 * x + 2] = (uint8_t)v;
+            } else {
+                out[3 * x] = (uint8_t)sample(0); out[3 * x + 1] = (uint8_t)sample(1); out[3 * x + 2] = (uint8_t)sample(2);
+            }
+        }
+        prev.swap(line);
+    }
+    w = W;
+    h = H;
+    return true;
+}
+bool read_image_rgb8(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h) {
+    return read_ppm(path, rgb, w, h) || read_png(path, rgb, w, h);
+}
 TexturePtr ImageTexture::new_or_fallback(const std::string& path) {
     std::vector<uint8_t> rgb;
     uint32_t w = 0, h = 0;
-    if (read_ppm(path, rgb, w, h)) return from_rgb8(rgb.data(), w, h);
+    if (read_image_rgb8(path, rgb, w, h)) return from_rgb8(rgb.data(), w, h);
     std::fprintf(stderr, "Could not load the image texture %s. Falling back to default.\n", path.c_str());
     return CheckerTexture::from_colors(2.0, Color(1.0, 0.0, 0.862745098039), Color(0.00392156862745, 0.0, 0.00392156862745));
 }
@@ -814,10 +914,21 @@ int Camera::render(const Hittable& world, rt_stats* stats) const {
     size_t npix = (size_t)cam.width * cam.height;
     std::vector<double> film(3 * npix);
     std::vector<uint8_t> rgb(3 * npix);
-    int rc = rt_render(s, &cam, &o, film.data(), stats);
+    rt_stats local;
+    rt_stats* stats_or_local = stats ? stats : &local;
+    int rc = rt_render(s, &cam, &o, film.data(), stats_or_local);
     if (rc == RT_OK) rc = rt_tonemap_rgb8(s, film.data(), cam.width, cam.height, samples_per_pixel, rgb.data());
     if (rc != RT_OK) std::fprintf(stderr, "render failed: %s\n", rt_last_error());
     rt_scene_destroy(s);
+    if (rc == RT_OK && metrics && stats_or_local) {
+        // one JSON line where the reference prints its banners and progress bar (camera.rs:252,256,269)
+        const rt_stats& t = *stats_or_local;
+        std::fprintf(metrics, "{\"event\": \"render_done\", \"width\": %u, \"height\": %u, \"spp\": %u, \"max_depth\": %u, "
+                              "\"paths\": %llu, \"rays\": %llu, \"ms\": %.3f, \"mrays_per_s\": %.3f, \"output\": \"%s\"}\n",
+                     cam.width, cam.height, samples_per_pixel, max_depth, (unsigned long long)t.paths, (unsigned long long)t.rays,
+                     t.ms_total, t.ms_total > 0 ? (double)t.rays / t.ms_total * 1e-3 : 0.0, output_path.c_str());
+        std::fflush(metrics);
+    }
     if (rc == RT_OK && !write_png(output_path, rgb.data(), cam.width, cam.height)) {
         std::fprintf(stderr, "could not write %s\n", output_path.c_str());
         return RT_ERR_INVALID;

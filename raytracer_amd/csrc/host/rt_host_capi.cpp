@@ -235,6 +235,36 @@ void rth_camera_new(double aspect_ratio, uint32_t image_width, double vfov, doub
         std::memset(out, 0, sizeof *out);  // (an image of width 0 is refused by every render call)
     }
 }
+int rth_thrender(rth_builder* b, int world, const rt_camera* cam, uint32_t spp, uint32_t max_depth, const double* background,
+                 uint64_t seed, int device, const char* output_path, int print_metrics, rt_stats* stats) {
+    NEEDB; OBJ(world);
+    if (!cam || !background || !output_path) return bad(b, "null argument");
+    GUARD(
+        Camera c = Camera::create(1.0, 1, ImageQuality{spp, max_depth}, 40.0, ThinLens{0.0, 1.0},
+                                  CameraPosition{Point3(0, 0, 1), Point3(0, 0, 0), Point3(0, 1, 0)}, p3(background));
+        c.cam = *cam;
+        c.seed = seed;
+        c.device = device;
+        c.output_path = output_path;
+        c.metrics = print_metrics ? stdout : nullptr;
+        const int rc = c.thrender(*b->objects[world], stats);
+        if (rc != 0) b->err = rt_last_error();
+        return rc;)
+}
+int rth_read_image(const char* path, uint8_t* rgb8, uint64_t capacity, uint32_t* w, uint32_t* h) {
+    if (!path || !w || !h) return -1;
+    try {
+        std::vector<uint8_t> rgb;
+        if (!read_image_rgb8(path, rgb, *w, *h)) return -1;
+        if (rgb8) {
+            if (capacity < rgb.size()) return -1;
+            std::memcpy(rgb8, rgb.data(), rgb.size());
+        }
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
 int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
     if (!path || !rgb8 || !w || !h) return -1;
     try {

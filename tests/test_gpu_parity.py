@@ -216,6 +216,7 @@ def test_image_rmse_gpu_vs_oracle_at_equal_spp(gpu_scenes):
         b = orc.tonemap(want, spp).astype(np.float64)
         rmse = np.sqrt(np.mean((a - b) ** 2))
         off = (np.abs(a - b).max(axis=2) > 1).mean()
+        print(cfg, "rmse", rmse, "off", off)
         assert rmse < rmse_max, (cfg, rmse)
         assert off < off_max, (cfg, off)
         assert 20 * np.log10(255.0 / max(rmse, 1e-9)) > 36.0  # PSNR
