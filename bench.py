@@ -99,6 +99,46 @@ def profiled(config):
         return json.load(fh).get(config, {})
 
 
+def fast_bvh_report(scene, cam, spec, film, spp, parity_rate):
+    """RT_FLAG_FAST_BVH (nearest-first traversal, not the default): its rate on the same workload at a bounded sample
+    count, and how often it reports another primitive than the parity mode -- on camera rays through random pixels and
+    on rays scattered from their hit points, through rt_intersect_batch."""
+    import numpy as np
+    rs = np.random.RandomState(7)
+    n = 200_000
+    px = rs.uniform(0, cam.width, n)
+    py = rs.uniform(0, cam.height, n)
+    c = np.array(cam.center[:])
+    d = (np.array(cam.pixel00[:])[None, :] + px[:, None] * np.array(cam.delta_u[:])[None, :] +
+         py[:, None] * np.array(cam.delta_v[:])[None, :]) - c[None, :]
+    o = np.repeat(c[None, :], n, axis=0)
+    total = differing = 0
+    for _ in range(2):
+        scene.set_fast_bvh(False)
+        a = scene.intersect(o, d, 0.001, np.inf)
+        scene.set_fast_bvh(True)
+        b = scene.intersect(o, d, 0.001, np.inf)
+        scene.set_fast_bvh(False)
+        total += len(o)
+        differing += int((a["prim"] != b["prim"]).sum())
+        hit = a["hit"] == 1
+        if not hit.any():
+            break
+        v = rs.standard_normal((int(hit.sum()), 3))
+        o, d = a["p"][hit], a["n"][hit] + v / np.linalg.norm(v, axis=1, keepdims=True)
+    sub = max(1, min(spp, 200))
+    scene.render_into(cam, sub, spec.max_depth, spec.background, film.data_ptr(), fast_bvh=True)  # warm-up
+    t0 = time.perf_counter()
+    st = scene.render_into(cam, sub, spec.max_depth, spec.background, film.data_ptr(), fast_bvh=True)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    st0 = scene.render_into(cam, sub, spec.max_depth, spec.background, film.data_ptr())
+    dt0 = time.perf_counter() - t0
+    return {"flag": "RT_FLAG_FAST_BVH (opt-in, not the reference's tie rule)", "prim_id_mismatch_rate": differing / max(total, 1),
+            "rays_compared": total, "value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "spp": sub,
+            "parity_mode_same_spp": st0["rays"] / dt0 / 1e6, "speedup": (st["rays"] / dt) / (st0["rays"] / dt0)}
+
+
 def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_rank, world, with_cpu):
     """Times `steps` renders of one workload; returns the JSON fields of that workload (rank 0) or None."""
     from raytracer_amd import HostBuilder, camera_new, scenes
@@ -127,7 +167,7 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
         def render_range(begin, count):
             st.update(scene.render_into(cam, count, spec.max_depth, spec.background, film.data_ptr(), spp_begin=begin,
                                         batch_paths=args.batch_paths, whole_paths=schedule,
-                                        split_bounce=args.split_bounce))
+                                        split_bounce=args.split_bounce, fast_bvh=args.fast_bvh))
 
         render_sharded(render_range, film, spp_job)  # this rank's contiguous share of the job's samples, then all-reduce
         return st
@@ -246,6 +286,8 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
             out["roofline_hbm"] = hbm
     else:
         out["roofline"] = None
+    if stats and not stats[0]["lockstep"] and world == 1:
+        out["fast_bvh"] = fast_bvh_report(scene, cam, spec, film, spp, out["value"])
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(key, width)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
@@ -264,6 +306,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--fast-bvh", action="store_true", help="RT_FLAG_FAST_BVH for the timed steps (invalidates the metric: "
+                    "ties between primitives are not decided as the reference decides them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the BVH workloads timed after the headline one")
     ap.add_argument("--also-c5-spp", type=int, default=1000, help="samples per pixel of the C5 entry under \"also\"")

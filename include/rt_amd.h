@@ -150,6 +150,14 @@ typedef struct rt_render_opts {
                                     launch per bounce, as for scenes with BVH entries, instead of the single bounce
                                     kernel that does both (the default there).  The film is the same either way */
 
+#define RT_FLAG_FAST_BVH 32u /* NOT the reference's result in every case.  BVH entries whose leaves the library walks
+                                through its own four-wide tree visit that tree's children nearest first instead of in the
+                                reference's fixed order (upper half first, bvh.rs:50-57,127-130): fewer boxes and
+                                primitives are looked at before the closest hit is known.  The closest hit is the same
+                                except where two primitives are hit at exactly the same parameter: the reference's
+                                order decides such ties (hittable_list.rs:94-96), this mode lets the first one found
+                                win.  Never the default; bench.py reports the rate of differing primitive ids */
+
 typedef struct rt_stats {
     uint64_t paths;      /* camera samples traced */
     uint64_t rays;       /* world.hit calls: one per bounce including the camera ray (camera.rs:363,429) */
@@ -217,6 +225,9 @@ int rt_scene_set_nodes(rt_scene* s, const rt_node* nodes, uint32_t n_nodes, cons
 int rt_scene_set_cull_boxes(rt_scene* s, const double* tight6, uint32_t n_boxes);
 /* Validates the description and uploads it to HIP device `device`. */
 int rt_scene_commit(rt_scene* s, int device);
+/* RT_FLAG_FAST_BVH for every later call on this scene, rt_intersect_batch included (which takes no flags); on = 0
+ * switches it off again.  No counterpart in the reference. */
+int rt_scene_set_fast_bvh(rt_scene* s, int on);
 
 /* ---- Hittable::hit on a batch of rays (hittable/mod.rs:65-68) ----------------------------------------
  * Ray i is (o3[3i..], d3[3i..]) with interval tmin[i]..tmax[i] (camera.rs:363 uses 0.001..inf).  rng3, if not

@@ -63,6 +63,7 @@ RT_FLAG_NO_CULL = 2
 RT_FLAG_WHOLE_PATHS = 4
 RT_FLAG_QUEUES = 8
 RT_FLAG_SPLIT_BOUNCE = 16
+RT_FLAG_FAST_BVH = 32
 RT_NO_HIT = 0xFFFFFFFF
 NODE_KINDS = {0: "bvh", 1: "medium", 2: "spheres", 3: "quads", 4: "triangles", 5: "quadrics", 6: "cull"}
 
@@ -73,6 +74,7 @@ RT_AMD_SYMBOLS = [
     "rt_scene_set_triangles", "rt_scene_set_quadrics", "rt_scene_set_media", "rt_scene_set_xforms",
     "rt_scene_set_nodes", "rt_scene_set_cull_boxes", "rt_scene_commit", "rt_intersect_batch", "rt_render", "rt_render_device",
     "rt_render_multi", "rt_trace_samples", "rt_tonemap_rgb8", "rt_debug_arith", "rt_intersect_batch_noalloc",
+    "rt_scene_set_fast_bvh",
 ]
 
 _amd = None
@@ -110,6 +112,7 @@ def amd():
     L.rt_scene_set_nodes.argtypes = [vp, vp, u32, vp, u32]
     L.rt_scene_set_cull_boxes.argtypes = [vp, vp, u32]
     L.rt_scene_commit.argtypes = [vp, i32]
+    L.rt_scene_set_fast_bvh.argtypes = [vp, i32]
     L.rt_intersect_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_intersect_batch_noalloc.argtypes = [vp, u64, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), vp, C.POINTER(rt_stats)]

@@ -186,6 +186,7 @@ struct TravArgs {
     const uint32_t* wl;       // gated launch: the queue slots to work on and where their number is; null: every ray
     const uint32_t* wl_count;
     int thr_fetch, thr_step;  // wide kernel: lanes that must be waiting before rays are handed out / a step is taken
+    uint32_t fast;            // wide kernel: children nearest first (RT_FLAG_FAST_BVH)
 };
 __device__ __forceinline__ Best trav_best_setup(const TravArgs& a, uint32_t idx) {
     Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
@@ -934,6 +935,7 @@ struct rt_scene {
     bool committed = false;
     int device = -1;
     uint32_t levels = 0;  // interval slots per lane the walk needs
+    bool fast_bvh = false; // rt_scene_set_fast_bvh
     bool has_bvh = false; // selects the traverse kernel: lockstep (no BVH entries) or persistent
     // A tree with BVH entries is walked in stretches of whole top-level entries: those without a BVH entry below them
     // (every ray does the same work there) by the lockstep kernel, the others by the persistent one; the closest hit
@@ -1003,6 +1005,12 @@ void rt_scene_destroy(rt_scene* s) {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
     delete s;
+}
+
+int rt_scene_set_fast_bvh(rt_scene* s, int on) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    s->fast_bvh = on != 0;
+    return RT_OK;
 }
 
 #define NEED_UNCOMMITTED(s)                                                        \
@@ -1291,7 +1299,7 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
         if ((rc = upload(s, w.items, &di))) return rc;
         dw.items = reinterpret_cast<const uint4*>(di);
         for (int ax = 0; ax < 3; ++ax) { dw.base[ax] = w.base[ax]; dw.step[ax] = w.step[ax]; }
-        dw.K = w.K; dw.lambda = w.lambda; dw.chain = w.chain;
+        dw.K = w.K; dw.lambda = w.lambda; dw.chain = w.chain; dw.fast = 0u;
         s->d_wide.push_back(dw);
     }
     {
@@ -1432,8 +1440,10 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
             static const int ts = getenv("RT_WIDE_TS") ? atoi(getenv("RT_WIDE_TS")) : RT_WIDE_STEP_THRESHOLD;
             a.thr_fetch = tf; a.thr_step = ts;
             static const bool prof = getenv("RT_WIDE_PROF") != nullptr;
-            if (prof) hipLaunchKernelGGL(k_traverse_wide<true>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, work, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3));
-            else hipLaunchKernelGGL(k_traverse_wide<false>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, s->d_wide[(size_t)st.wide], a, work, nullptr);
+            DWide dw = s->d_wide[(size_t)st.wide];
+            dw.fast = (a_.fast || s->fast_bvh) ? 1u : 0u;
+            if (prof) hipLaunchKernelGGL(k_traverse_wide<true>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3));
+            else hipLaunchKernelGGL(k_traverse_wide<false>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, nullptr);
         } else if (st.kind == RT_STRETCH_LOCKSTEP) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
             if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
@@ -1867,6 +1877,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 std::memset(&ta, 0, sizeof ta);
                 ta.q = qin; ta.hb = hb_in; ta.seed = o->seed; ta.segs = segs;
                 if (gated) { ta.resume = 1u; ta.wl = s->wl; ta.wl_count = segs.in_count; }
+                ta.fast = (o->flags & RT_FLAG_FAST_BVH) ? 1u : 0u;
                 if ((rc = launch_traverse(s, ta, count, nocull, upper_in))) return rc;
                 HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
                 const uint32_t sblocks = (upper_in + SHADE_BLOCK - 1) / SHADE_BLOCK + nclass + 1u;

@@ -31,14 +31,17 @@
 namespace rt {
 
 struct DWide {               // as the kernels see it
-    const uint4* nodes;      // 64 bytes per node, 48 used: the four child boxes, 6 x u16 each (x, y, z: start, end) on
-                             // the grid base + q * step of the tree's bounds, starts rounded down and ends up
+    const uint4* nodes;      // 64 bytes per node: the four child boxes, 6 x u16 each (x, y, z: start, end) on the grid
+                             // base + q * step of the tree's bounds, starts rounded down and ends up (48 bytes); then
+                             // one word: the axis along which children 0, 1 lie beyond children 2, 3
     const uint4* items;      // per level-1 node: its four items as (first primitive, kind << 24 | count)
     const double2* refbox;   // per leaf: the reference's box, 3 x (start, end)
     double base[3], step[3]; // the grid
     uint32_t K;              // the root is node (K, 0)
     uint32_t lambda;         // a leaf covers 4^lambda item slots
     uint32_t chain;          // the instance chain the whole tree lives in
+    uint32_t fast;           // 1: children are visited nearest first (see wide_node_step); results then differ from the
+                             // reference's where two primitives are hit at exactly the same parameter
 };
 RT_HD uint32_t wide_node_index(uint32_t K, uint32_t k, uint32_t g) {
     return (0x55555555u & ((1u << (2u * (K - k))) - 1u)) + g;  // (4^(K-k) - 1) / 3 nodes lie above level k
@@ -224,6 +227,28 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
                 }
                 if (k == 1) { out.items[8 * g + 2 * j] = desc[2 * (4 * g + j)]; out.items[8 * g + 2 * j + 1] = desc[2 * (4 * g + j) + 1]; }
             }
+            {   // The reference splits a node along its longest axis and visits the upper half first (bvh.rs:118-130),
+                // so children 0, 1 usually lie beyond children 2, 3 along one axis: the one along which the centres of
+                // the two pairs are farthest apart.  Only the nearest-first order of the fast mode reads it.
+                double c[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                int have[2] = {0, 0};
+                for (int j = 0; j < 4; ++j) {
+                    const double* b = &lv[k - 1][6 * (4 * g + j)];
+                    if (!(b[0] <= b[1])) continue;
+                    for (int a = 0; a < 3; ++a) c[j / 2][a] += 0.5 * (b[2 * a] + b[2 * a + 1]);
+                    have[j / 2]++;
+                }
+                uint32_t axis = 0;
+                if (have[0] && have[1]) {
+                    double best = -1.0;
+                    for (int a = 0; a < 3; ++a) {
+                        const double sep = std::fabs(c[0][a] / have[0] - c[1][a] / have[1]);
+                        if (sep > best) { best = sep; axis = (uint32_t)a; }
+                    }
+                    if (c[0][axis] / have[0] < c[1][axis] / have[1]) axis |= 4u;  // children 0, 1 are the LOWER ones here
+                }
+                reinterpret_cast<uint32_t*>(rec)[12] = axis;
+            }
         }
     }
     return true;
@@ -268,6 +293,7 @@ struct WLane {
     double s, e;              // inside a leaf: the interval its box narrowed that to, e shortened by every hit since
     Best best;
     unsigned long long pending;  // bits 4k .. 4k + 3: children of the level-k node above the cursor still to be visited
+    uint32_t rev;                // fast mode: bit k set = the level-k node's children are taken from 3 down to 0
     uint32_t slot, level;     // the node to look at next is (level, slot >> 2 level)
     uint32_t k, kend, kind;   // run in progress; kind bit 9: the leaf's box has yet to narrow the interval (lambda = 0)
     uint32_t d0x, d0y, d1x, d1y, d2x, d2y, d3x, d3y;  // the items of the level-1 node above the cursor
@@ -299,6 +325,7 @@ RT_HD void wide_begin(WLane& ln, const DScene& S, const DWide& W, const Ray& wor
     ln.tmin = tmin; ln.tmax = tmax; ln.s = tmin; ln.e = tmax;
     ln.best = best;
     ln.pending = 0ull;
+    ln.rev = 0u;
     ln.slot = 0u; ln.level = W.K;
     ln.k = ln.kend = 0u; ln.kind = 0u;
     ln.d0x = ln.d0y = ln.d1x = ln.d1y = ln.d2x = ln.d2y = ln.d3x = ln.d3y = 0u;
@@ -331,8 +358,15 @@ RT_HD uint32_t ctz64(unsigned long long x) {
 RT_HD void wide_ascend(WLane& ln, const DWide& W) {
     const bool none = ln.pending == 0ull;
     const uint32_t p = none ? 4u : ctz64(ln.pending);
-    ln.pending &= ln.pending - 1ull;  // (0 stays 0)
-    wide_goto(ln, W, p >> 2, p & 3u);
+    const uint32_t k = p >> 2;
+    uint32_t j = p & 3u;
+    if (W.fast) {  // the farthest-numbered child first where the node's order is reversed
+        const uint32_t g = (uint32_t)(ln.pending >> (4u * k)) & 15u;
+        const uint32_t top = g >= 8u ? 3u : (g >= 4u ? 2u : (g >= 2u ? 1u : 0u));
+        j = ((ln.rev >> k) & 1u) != 0u && !none ? top : j;
+    }
+    ln.pending &= ~((none ? 0ull : 1ull) << (4u * k + j));
+    wide_goto(ln, W, k, j);
     ln.state = none ? RT_W_DONE : ln.state;
 }
 // Whether the ray's interval (s, e) may touch a child box, given as three words of two u16 grid values (x, y, z:
@@ -346,6 +380,8 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln) {
     const uint32_t k = ln.level;
     const uint4* rp = W.nodes + 4u * wide_node_index(W.K, k, ln.slot >> (2u * k));
     const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    uint32_t axis = 0u;
+    if (W.fast) axis = rp[3].x;
     if (k == 1u) {
         const uint4* ip = W.items + 2u * (ln.slot >> 2);
         const uint4 a = ip[0], b = ip[1];
@@ -374,11 +410,26 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln) {
     if (wide_box(q2.y, q2.z, q2.w, ln, cs, ce)) m |= 8u;
     if (m == 0u) { wide_ascend(ln, W); return; }
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t j = (uint32_t)(__ffs((int)m) - 1);
+    uint32_t j = (uint32_t)(__ffs((int)m) - 1);
 #else
-    const uint32_t j = (uint32_t)__builtin_ctz(m);
+    uint32_t j = (uint32_t)__builtin_ctz(m);
 #endif
-    m &= m - 1u;
+    if (W.fast) {
+        // Nearest first: children 0, 1 lie beyond (axis bit 2: before) children 2, 3 along `axis`, so a ray that runs
+        // up that axis meets 2, 3 first.  Whatever the order, every child whose box the interval can touch is visited
+        // unless a closer hit has shortened the interval meanwhile; only hits at exactly equal parameters can come out
+        // differently from the reference's order.
+        // (comparisons first, then the choice between their results: a choice between the fields themselves would be
+        // turned into a load through a selected address, and the lane state would live in scratch memory)
+        const bool px = ln.cur.d.x > 0.0, py = ln.cur.d.y > 0.0, pz = ln.cur.d.z > 0.0;
+        const uint32_t a = axis & 3u;
+        const bool up = (a == 0u && px) || (a == 1u && py) || (a == 2u && pz);
+        const bool reversed = ((axis & 4u) != 0u) != up;
+        const uint32_t top = m >= 8u ? 3u : (m >= 4u ? 2u : (m >= 2u ? 1u : 0u));
+        j = reversed ? top : j;
+        ln.rev = (ln.rev & ~(1u << k)) | ((reversed ? 1u : 0u) << k);
+    }
+    m &= ~(1u << j);
     ln.pending |= (unsigned long long)m << (4u * k);
     wide_goto(ln, W, k, j);
 }

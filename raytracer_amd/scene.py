@@ -16,12 +16,12 @@ def _opts(spp_begin, spp_count, max_depth, seed, background, batch_paths=0, flag
     return o
 
 
-def _flags(counters, cull, whole_paths, split_bounce=False):
+def _flags(counters, cull, whole_paths, split_bounce=False, fast_bvh=False):
     """whole_paths: None = the library's choice, True / False = force one kernel per batch / the queue schedule;
     split_bounce: a traverse and a shade launch per bounce where the queue schedule would use one bounce kernel."""
     return ((_lib.RT_FLAG_COUNTERS if counters else 0) | (0 if cull else _lib.RT_FLAG_NO_CULL) |
             (0 if whole_paths is None else (_lib.RT_FLAG_WHOLE_PATHS if whole_paths else _lib.RT_FLAG_QUEUES)) |
-            (_lib.RT_FLAG_SPLIT_BOUNCE if split_bounce else 0))
+            (_lib.RT_FLAG_SPLIT_BOUNCE if split_bounce else 0) | (_lib.RT_FLAG_FAST_BVH if fast_bvh else 0))
 
 
 def _stats_dict(st):
@@ -69,7 +69,7 @@ class Scene:
         return out
 
     def render(self, cam, spp, max_depth, background, seed=42, spp_begin=0, batch_paths=0, counters=False,
-               cull=True, whole_paths=None, split_bounce=False):
+               cull=True, whole_paths=None, split_bounce=False, fast_bvh=False):
         """Camera::render: returns (film of radiance SUMS, shape (H, W, 3), stats dict).  cull=False switches the
         cull boxes off: the same film from exactly the box and primitive tests the reference performs.
         whole_paths=True traces whole paths in one kernel (scenes without BVH entries only), False forces the
@@ -77,17 +77,21 @@ class Scene:
         of a scene without BVH entries use a traverse and a shade launch per bounce instead of its one bounce kernel."""
         film = np.zeros((cam.height, cam.width, 3))
         st = rt_stats()
-        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths, split_bounce))
+        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths, split_bounce, fast_bvh))
         self._ck(self.L.rt_render(self.h, C.byref(cam), C.byref(o), film.ctypes.data, C.byref(st)))
         return film, _stats_dict(st)
 
     def render_into(self, cam, spp, max_depth, background, film_device_ptr, seed=42, spp_begin=0, batch_paths=0,
-                    counters=False, cull=True, whole_paths=None, split_bounce=False):
+                    counters=False, cull=True, whole_paths=None, split_bounce=False, fast_bvh=False):
         """Same, into a caller-owned device buffer of H*W*3 f64 (e.g. a torch tensor's data_ptr())."""
         st = rt_stats()
-        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths, split_bounce))
+        o = _opts(spp_begin, spp, max_depth, seed, background, batch_paths, _flags(counters, cull, whole_paths, split_bounce, fast_bvh))
         self._ck(self.L.rt_render_device(self.h, C.byref(cam), C.byref(o), film_device_ptr, C.byref(st)))
         return _stats_dict(st)
+
+    def set_fast_bvh(self, on):
+        """RT_FLAG_FAST_BVH for every later call on this scene (rt_intersect_batch takes no flags)."""
+        self._ck(self.L.rt_scene_set_fast_bvh(self.h, 1 if on else 0))
 
     def trace_samples(self, cam, pixel, sample, max_depth, background, seed=42):
         pixel = np.ascontiguousarray(pixel, dtype=np.uint32)

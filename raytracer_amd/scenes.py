@@ -365,10 +365,15 @@ def debug_model(b, seed=42, width=600, spp=20, model_path=None):
     return _model_scene("debug_model", b, model_path or os.path.join(ASSETS, "pawn.obj"), (0.0, 0.0, 2.0), width, spp)
 
 
-def bust(b, seed=42, width=600, spp=20, model_path=None):
-    """main.rs:1326-1371.  As debug_model from 200 units away; the reference's mesh (models/Emperor.obj) is not part
-    of its repository, so a path has to be given (the teapot stands in by default)."""
-    return _model_scene("bust", b, model_path or os.path.join(ASSETS, "teapot.obj"), (0.0, 0.0, 200.0), width, spp)
+def bust(b, seed=42, width=600, spp=20, model_path=None, triangles=766_484):
+    """main.rs:1326-1371.  As debug_model from 200 units away.  The reference's meshes (models/Emperor.obj, or
+    models/David.obj with 766 484 triangles, main.rs:1330-1331) are not part of its repository: unless a path is
+    given, a procedural mesh of `triangles` triangles (raytracer_amd.meshgen) is written to a temporary .obj and goes
+    through load_model like any other file."""
+    if model_path is None:
+        from .meshgen import cached_bust
+        model_path = cached_bust(triangles)
+    return _model_scene("bust", b, model_path, (0.0, 0.0, 200.0), width, spp)
 
 
 # BASELINE.json configs, in order

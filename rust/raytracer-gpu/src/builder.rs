@@ -310,6 +310,11 @@ impl GpuScene {
     pub fn as_ptr(&self) -> *const RtScene {
         self.ptr
     }
+    /// `RT_FLAG_FAST_BVH` for every later call: nearest-first traversal, which is not the reference's result where two
+    /// primitives are hit at exactly the same parameter.
+    pub fn set_fast_bvh(&self, on: bool) -> Result<(), GpuError> {
+        check(unsafe { rt_scene_set_fast_bvh(self.ptr, on as c_int) })
+    }
     /// `Camera::render`: the film of radiance SUMS over samples `[spp_begin, spp_begin + spp_count)`, 3 f64 per pixel.
     pub fn render(&self, cam: &RtCamera, opts: &RtRenderOpts) -> Result<(Vec<f64>, RtStats), GpuError> {
         let mut film = vec![0f64; 3 * cam.width as usize * cam.height as usize];

@@ -39,6 +39,7 @@ pub const RT_FLAG_NO_CULL: u32 = 2;
 pub const RT_FLAG_WHOLE_PATHS: u32 = 4;
 pub const RT_FLAG_QUEUES: u32 = 8;
 pub const RT_FLAG_SPLIT_BOUNCE: u32 = 16;
+pub const RT_FLAG_FAST_BVH: u32 = 32;
 
 /// Opaque `rt_scene`.
 #[repr(C)]
@@ -168,6 +169,7 @@ extern "C" {
     pub fn rt_scene_set_nodes(s: *mut RtScene, nodes: *const RtNode, n_nodes: u32, boxes6: *const f64, n_boxes: u32) -> c_int;
     pub fn rt_scene_set_cull_boxes(s: *mut RtScene, tight6: *const f64, n_boxes: u32) -> c_int;
     pub fn rt_scene_commit(s: *mut RtScene, device: c_int) -> c_int;
+    pub fn rt_scene_set_fast_bvh(s: *mut RtScene, on: c_int) -> c_int;
     pub fn rt_intersect_batch(s: *const RtScene, seed: u64, o3: *const f64, d3: *const f64, tmin: *const f64, tmax: *const f64, rng3: *const u32, n: u64, hit: *mut u8, prim: *mut u32, t: *mut f64, p3: *mut f64, n3: *mut f64, uv2: *mut f64, front: *mut u8, ctr_out: *mut u32) -> c_int;
     pub fn rt_intersect_batch_noalloc(s: *const RtScene, seed: u64, od6_dev: *const f64, tmin_dev: *const f64, tmax_dev: *const f64, rng3_dev: *mut u32, n: u32, hit_dev: *mut u8, prim_dev: *mut u32, t_dev: *mut f64, p3_dev: *mut f64, n3_dev: *mut f64, uv2_dev: *mut f64, front_dev: *mut u8) -> c_int;
     pub fn rt_render(s: *const RtScene, cam: *const RtCamera, opts: *const RtRenderOpts, film_rgb: *mut f64, stats: *mut RtStats) -> c_int;

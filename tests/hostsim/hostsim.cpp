@@ -67,6 +67,8 @@ extern "C" void sim_set_uniform_mode(int on) { host_uniform_mode() = on != 0; }
 extern "C" void sim_set_walk_mode(int m) { mode = m; }
 extern "C" void sim_set_cull(int on) { use_cull = on; }
 extern "C" void sim_set_one_pass(int on) { use_one_pass = on; }
+static int use_fast = 0;  // wide trees: children nearest first (RT_FLAG_FAST_BVH)
+extern "C" void sim_set_fast_bvh(int on) { use_fast = on; }
 static int use_sig = 1;  // lockstep walk: 0 leaves every ray's signature at all ones (nothing is passed over)
 extern "C" void sim_set_signatures(int on) { use_sig = on; }
 extern "C" unsigned long long sim_fallbacks(void) { return host_fallback_count(); }
@@ -114,7 +116,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
                     W.refbox = reinterpret_cast<const double2*>(wb.refbox.data());
                     W.items = reinterpret_cast<const uint4*>(wb.items.data());
                     for (int ax = 0; ax < 3; ++ax) { W.base[ax] = wb.base[ax]; W.step[ax] = wb.step[ax]; }
-                    W.K = wb.K; W.lambda = wb.lambda; W.chain = wb.chain;
+                    W.K = wb.K; W.lambda = wb.lambda; W.chain = wb.chain; W.fast = (uint32_t)use_fast;
                     WLane wl;
                     wide_begin(wl, S, W, w, tmin[i], tmax[i], b);
                     while (wl.state != RT_W_DONE) {

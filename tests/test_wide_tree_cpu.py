@@ -135,3 +135,29 @@ def test_wide_tree_over_mixed_leaves_and_fallback_for_other_trees():
     finally:
         L.sim_set_walk_mode(0)
     assert_hits_equal(got, want, exact=True, what="mixed scene")
+
+
+@pytest.mark.parametrize("cfg", sorted(BVH_CONFIGS))
+def test_nearest_first_order_finds_the_same_hits_with_fewer_tests(pairs, cfg):
+    """RT_FLAG_FAST_BVH visits a wide tree's children nearest first.  The closest hit is the same wherever no two
+    primitives are hit at exactly the same parameter (on these scenes: everywhere, bar the shared faces of the floor
+    boxes of final_scene, where either box may be reported); fewer primitives are tested on the way."""
+    hs, os_, sim = pairs(cfg)
+    L = _stretch_mode()
+    _, oc = cameras(hs)
+    o, d, rng3 = path_rays(os_, oc, 6000, 1)
+    want = os_.builder.intersect(o, d, 0.001, np.inf, rng3)
+    L.sim_set_walk_mode(3)
+    try:
+        plain = sim.intersect(o, d, 0.001, np.inf, rng3)
+        L.sim_set_fast_bvh(1)
+        fast = sim.intersect(o, d, 0.001, np.inf, rng3)
+    finally:
+        L.sim_set_fast_bvh(0)
+        L.sim_set_walk_mode(0)
+    assert_hits_equal(plain, want, exact=True, what=cfg)
+    assert np.array_equal(fast["hit"], want["hit"]) and np.array_equal(fast["t"], want["t"])
+    differing = (fast["prim"] != want["prim"]).mean()
+    print(cfg, "prim ids differing in fast mode:", differing, "prim tests", fast["counters"]["prim_tests"], "vs", plain["counters"]["prim_tests"])
+    assert differing <= (0.01 if cfg == "C5" else 0.0)
+    assert fast["counters"]["prim_tests"] <= plain["counters"]["prim_tests"]

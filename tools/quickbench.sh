@@ -10,7 +10,7 @@ for c in $cfgs; do
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); r=d['roofline']
-    print(d['config']['workload'][:22], 'Mrays/s %.0f'%d['value'], 'Mpaths/s %.0f'%d['mpaths_per_s'], 'ms/step %.1f'%d['ms_per_step'], 'kernel_share %.2f'%r['kernel_share_of_step'], 'shade_ms %.1f'%r['shade_ms_per_step'], 'avg_launch_ms %.3f'%r['avg_launch_ms'], 'fp64 frac %.3f / %.3f'%(r['frac_algorithmic'],r['frac_executed']))
+    print(d['config']['workload'][:22], 'Mrays/s %.0f'%d['value'], 'Mpaths/s %.0f'%d['mpaths_per_s'], 'ms/step %.1f'%d['ms_per_step'], 'kernel_share %.2f'%r['kernel_share_of_step'], 'shade_ms %.1f'%r['shade_ms_per_step'], 'avg_launch_ms %.3f'%r['avg_launch_ms'], 'fp64 frac %.3f / %.3f'%(r['frac_algorithmic'],r['frac_executed']), ('fast x%.2f mismatch %.2e'%(d['fast_bvh']['speedup'], d['fast_bvh']['prim_id_mismatch_rate'])) if 'fast_bvh' in d else '')
 " >> $out || exit 1
 done
 cat $out
