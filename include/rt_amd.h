@@ -151,7 +151,7 @@ typedef struct rt_render_opts {
                                     kernel that does both (the default there).  The film is the same either way */
 
 #define RT_FLAG_FAST_BVH 32u /* NOT the reference's result in every case.  BVH entries whose leaves the library walks
-                                through its own four-wide tree visit that tree's children nearest first instead of in the
+                                through its own eight-wide tree visit that tree's children nearest first instead of in the
                                 reference's fixed order (upper half first, bvh.rs:50-57,127-130): fewer boxes and
                                 primitives are looked at before the closest hit is known.  The closest hit is the same
                                 except where two primitives are hit at exactly the same parameter: the reference's

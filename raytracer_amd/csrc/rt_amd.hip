@@ -328,9 +328,9 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
     if (COUNT) tally_flush(tally, tallies);
 }
 
-// One top-level BVH entry whose leaves the four-wide tree of rt_wide.h covers: the same scheme as above -- a fixed grid
+// One top-level BVH entry whose leaves the eight-wide tree of rt_wide.h covers: the same scheme as above -- a fixed grid
 // of wavefronts pulls rays, every lane takes a new ray the moment its own is done -- with two kinds of step only, a
-// node of the wide tree (four child boxes, for a leaf's node the reference's narrowing first) or the next primitives of
+// node of the wide tree (eight child boxes, for a leaf's node the reference's narrowing first) or the next primitives of
 // an item.  The ray is taken into the tree's instance chain where it is handed out, by all lanes that take one
 // together; no random numbers are drawn here (no medium below such an entry).
 #define RT_WIDE_STEP_THRESHOLD 24
@@ -941,7 +941,7 @@ struct rt_scene {
     // (every ray does the same work there) by the lockstep kernel, the others by the persistent one; the closest hit
     // so far travels from one launch to the next in the hit buffer.
     std::vector<Stretch> stretches;
-    std::vector<WideBvh> wide;     // the four-wide trees of the BVH entries that take one (rt_wide.h)
+    std::vector<WideBvh> wide;     // the eight-wide trees of the BVH entries that take one (rt_wide.h)
     std::vector<DWide> d_wide;     // on the device
     GateInfo gate;                 // one gate per wide tree (the first RT_MAX_GATES of them): wide tree w has gate w
     const GateInfo* d_gate = nullptr;
@@ -1295,9 +1295,6 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
         if ((rc = upload(s, w.refbox, &db))) return rc;
         dw.nodes = reinterpret_cast<const uint4*>(dn);
         dw.refbox = reinterpret_cast<const double2*>(db);
-        const uint32_t* di = nullptr;
-        if ((rc = upload(s, w.items, &di))) return rc;
-        dw.items = reinterpret_cast<const uint4*>(di);
         for (int ax = 0; ax < 3; ++ax) { dw.base[ax] = w.base[ax]; dw.step[ax] = w.step[ax]; }
         dw.K = w.K; dw.lambda = w.lambda; dw.chain = w.chain; dw.fast = 0u;
         s->d_wide.push_back(dw);

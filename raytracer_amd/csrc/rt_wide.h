@@ -1,4 +1,4 @@
-// rt_wide.h -- a four-wide acceleration tree over the LEAVES of a reference BVH, and the per-lane walk that uses it.
+// rt_wide.h -- an eight-wide acceleration tree over the LEAVES of a reference BVH, and the per-lane walk that uses it.
 //
 // Why the reference's inner nodes can be replaced.  BVHNode::hit (bvh.rs:29-60) narrows the ray interval by its box
 // and hands the result to its children.  Every box is the union of the boxes of the objects below it (bvh.rs:88-92),
@@ -11,13 +11,13 @@
 // the tree otherwise; such a tree keeps the entry-by-entry walk of rt_core.h.
 //
 // The tree built here: the leaves in visiting order, each cut into items (a pair of triangles or quads with the box
-// around their corners, a whole run of spheres, one box-shaped list of quads, ...), every leaf padded to 4^lambda
-// item slots.  Above the items sits a complete 4-ary tree in heap order: node (k, g) covers slots
-// [g * 4^k, (g + 1) * 4^k) and holds the boxes of its four children as f32, rounded outwards (none of them narrows
-// anything: a subtree is passed over only when the ray's interval cannot touch the geometry below it).  A lane walks
-// it with a cursor that only moves forward, as the reference does, and remembers which children of the nodes above
-// it are still to be visited in four bits per level of one 64-bit register.  The level-lambda node of a leaf is where
-// the leaf's own f64 box does the reference's narrowing (for lambda = 0 the first primitive step does it).
+// around their corners, a whole run of spheres, one box-shaped list of quads, ...), every leaf padded to 8^lambda
+// item slots.  Above the items sits a complete 8-ary tree in heap order: node (k, g) covers slots
+// [g * 8^k, (g + 1) * 8^k) and holds the boxes of its eight children on a 16-bit grid, rounded outwards (none of
+// them narrows anything: a subtree is passed over only when the ray's interval cannot touch the geometry below it).
+// A lane walks it with a cursor that only moves forward, as the reference does, and remembers which children of the
+// nodes above it are still to be visited in eight bits per level of one 64-bit register.  The level-lambda node of a
+// leaf is where the leaf's own f64 box does the reference's narrowing (for lambda = 0 the first primitive step does).
 #pragma once
 
 #include "rt_core.h"
@@ -30,30 +30,35 @@
 
 namespace rt {
 
+#define RT_WIDE_LOG 3u                    // eight children per node
+#define RT_WIDE (1u << RT_WIDE_LOG)
+#define RT_WIDE_MAX_K 7u                  // eight pending bits per level (levels 1..7) in one 64-bit register
+
 struct DWide {               // as the kernels see it
-    const uint4* nodes;      // 64 bytes per node: the four child boxes, 6 x u16 each (x, y, z: start, end) on the grid
-                             // base + q * step of the tree's bounds, starts rounded down and ends up (48 bytes); then
-                             // one word: the axis along which children 0, 1 lie beyond children 2, 3
-    const uint4* items;      // per level-1 node: its four items as (first primitive, kind << 24 | count)
+    const uint4* nodes;      // 128 bytes per node: the eight child boxes, 6 x u16 each (x, y, z: start, end) on the grid
+                             // base + q * step of the tree's bounds, starts rounded down and ends up (96 bytes); then
+                             // four words: level-1 nodes: the first primitive of the node's first item | bits 0..7 the
+                             // items' primitive kind, bits 8..10 the axis along which children 0..3 lie beyond (bit 10:
+                             // before) children 4..7 | the eight items' primitive counts, a byte each (two words).  The
+                             // items of a level-1 node are consecutive runs of one array of primitives.
     const double2* refbox;   // per leaf: the reference's box, 3 x (start, end)
     double base[3], step[3]; // the grid
     uint32_t K;              // the root is node (K, 0)
-    uint32_t lambda;         // a leaf covers 4^lambda item slots
+    uint32_t lambda;         // a leaf covers 8^lambda item slots
     uint32_t chain;          // the instance chain the whole tree lives in
     uint32_t fast;           // 1: children are visited nearest first (see wide_node_step); results then differ from the
                              // reference's where two primitives are hit at exactly the same parameter
 };
 RT_HD uint32_t wide_node_index(uint32_t K, uint32_t k, uint32_t g) {
-    return (0x55555555u & ((1u << (2u * (K - k))) - 1u)) + g;  // (4^(K-k) - 1) / 3 nodes lie above level k
+    return (0x49249249u & ((1u << (RT_WIDE_LOG * (K - k))) - 1u)) + g;  // (8^(K-k) - 1) / 7 nodes lie above level k
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
 struct WideBvh {
     uint32_t entry = 0, end = 0, chain = 0, K = 0, lambda = 0, leaves = 0;
-    std::vector<uint32_t> nodes;  // 16 words per node
-    std::vector<uint32_t> items;  // 8 words per level-1 node
-    double base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
+    std::vector<uint32_t> nodes;  // 32 words per node
     std::vector<double> refbox;   // 6 per leaf
+    double base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
     double bounds[6] = {0, 0, 0, 0, 0, 0};  // of everything below the entry (x, y, z: start, end), in its chain
 };
 namespace wide_detail {
@@ -154,40 +159,39 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
     size_t most = 0;
     for (const Leaf& l : c.leaves) most = std::max(most, l.items.size());
     uint32_t lambda = 0;
-    while ((1ull << (2 * lambda)) < most) ++lambda;
-    if (lambda > 3) return false;
-    const uint64_t slots = (uint64_t)c.leaves.size() << (2 * lambda);
+    while ((1ull << (RT_WIDE_LOG * lambda)) < most) ++lambda;
+    if (lambda > 2) return false;
+    const uint64_t slots = (uint64_t)c.leaves.size() << (RT_WIDE_LOG * lambda);
     uint32_t K = std::max(1u, lambda);
-    while ((1ull << (2 * K)) < slots) ++K;
-    if (K > 12) return false;  // 16 M item slots; four pending bits per level fit one 64-bit register up to K = 15
+    while ((1ull << (RT_WIDE_LOG * K)) < slots) ++K;
+    if (K > RT_WIDE_MAX_K) return false;  // 2 M item slots
     out.entry = root; out.end = nodes[root].skip; out.chain = c.chain; out.K = K; out.lambda = lambda;
     out.leaves = (uint32_t)c.leaves.size();
     const double inf = std::numeric_limits<double>::infinity();
-    const size_t width = (size_t)1 << (2 * K);
-    std::vector<double> cur(6 * width);
-    for (size_t i = 0; i < width; ++i) for (int a = 0; a < 3; ++a) { cur[6 * i + 2 * a] = inf; cur[6 * i + 2 * a + 1] = -inf; }
+    const size_t width = (size_t)1 << (RT_WIDE_LOG * K);
+    // every level's boxes first (the grid needs the bounds of the whole tree), then the records
+    std::vector<std::vector<double>> lv(K + 1);
+    lv[0].assign(6 * width, 0.0);
+    for (size_t i = 0; i < width; ++i) for (int a = 0; a < 3; ++a) { lv[0][6 * i + 2 * a] = inf; lv[0][6 * i + 2 * a + 1] = -inf; }
     std::vector<uint32_t> desc(2 * width, 0u);
     out.refbox.resize(6 * c.leaves.size());
     for (size_t l = 0; l < c.leaves.size(); ++l) {
         std::memcpy(&out.refbox[6 * l], boxes + 6 * (size_t)c.leaves[l].box, 48);
         for (size_t i = 0; i < c.leaves[l].items.size(); ++i) {
             const Item& it = c.leaves[l].items[i];
-            const size_t slot = (l << (2 * lambda)) + i;
-            std::memcpy(&cur[6 * slot], it.box, 48);
+            const size_t slot = (l << (RT_WIDE_LOG * lambda)) + i;
+            std::memcpy(&lv[0][6 * slot], it.box, 48);
             desc[2 * slot] = it.first;
             desc[2 * slot + 1] = it.kind << 24 | it.count;
         }
     }
-    // every level's boxes first (the grid needs the bounds of the whole tree), then the records
-    std::vector<std::vector<double>> lv(K + 1);
-    lv[0].swap(cur);
     for (uint32_t k = 1; k <= K; ++k) {
-        const size_t count = lv[k - 1].size() / 24;
+        const size_t count = lv[k - 1].size() / (6 * RT_WIDE);
         lv[k].assign(6 * count, 0.0);
         for (size_t g = 0; g < count; ++g) {
             double u[6] = {inf, -inf, inf, -inf, inf, -inf};
-            for (int j = 0; j < 4; ++j) {
-                const double* b = &lv[k - 1][6 * (4 * g + j)];
+            for (uint32_t j = 0; j < RT_WIDE; ++j) {
+                const double* b = &lv[k - 1][6 * (RT_WIDE * g + j)];
                 if (b[0] <= b[1]) for (int a = 0; a < 3; ++a) { u[2 * a] = std::min(u[2 * a], b[2 * a]); u[2 * a + 1] = std::max(u[2 * a + 1], b[2 * a + 1]); }
             }
             std::memcpy(&lv[k][6 * g], u, 48);
@@ -202,15 +206,15 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
         out.base[a] = lo - 2.0 * out.step[a];
         if (!std::isfinite(out.step[a]) || !std::isfinite(out.base[a])) return false;
     }
-    const size_t total = (width - 1) / 3;
-    out.nodes.assign(16 * total, 0u);
-    out.items.assign(8 * (width / 4), 0u);
+    const size_t total = (width - 1) / (RT_WIDE - 1);
+    out.nodes.assign(32 * total, 0u);
     for (uint32_t k = 1; k <= K; ++k) {
         const size_t count = lv[k].size() / 6;
         for (size_t g = 0; g < count; ++g) {
-            uint16_t* rec = reinterpret_cast<uint16_t*>(&out.nodes[16 * (size_t)wide_node_index(K, k, (uint32_t)g)]);
-            for (int j = 0; j < 4; ++j) {
-                const double* b = &lv[k - 1][6 * (4 * g + j)];
+            uint32_t* words = &out.nodes[32 * (size_t)wide_node_index(K, k, (uint32_t)g)];
+            uint16_t* rec = reinterpret_cast<uint16_t*>(words);
+            for (uint32_t j = 0; j < RT_WIDE; ++j) {
+                const double* b = &lv[k - 1][6 * (RT_WIDE * g + j)];
                 for (int a = 0; a < 3; ++a) {
                     uint16_t q0 = 65535, q1 = 65535;  // no child: a box without extent, which no interval can touch
                     if (b[0] <= b[1]) {
@@ -225,30 +229,50 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
                     }
                     rec[6 * j + 2 * a] = q0; rec[6 * j + 2 * a + 1] = q1;
                 }
-                if (k == 1) { out.items[8 * g + 2 * j] = desc[2 * (4 * g + j)]; out.items[8 * g + 2 * j + 1] = desc[2 * (4 * g + j) + 1]; }
             }
+            uint32_t axis = 0;
             {   // The reference splits a node along its longest axis and visits the upper half first (bvh.rs:118-130),
-                // so children 0, 1 usually lie beyond children 2, 3 along one axis: the one along which the centres of
-                // the two pairs are farthest apart.  Only the nearest-first order of the fast mode reads it.
-                double c[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                // so the first half of a node's children usually lies beyond the second along one axis: the one along
+                // which the centres of the two halves are farthest apart.  Only the nearest-first order of the fast
+                // mode reads it.
+                double ctr[2][3] = {{0, 0, 0}, {0, 0, 0}};
                 int have[2] = {0, 0};
-                for (int j = 0; j < 4; ++j) {
-                    const double* b = &lv[k - 1][6 * (4 * g + j)];
+                for (uint32_t j = 0; j < RT_WIDE; ++j) {
+                    const double* b = &lv[k - 1][6 * (RT_WIDE * g + j)];
                     if (!(b[0] <= b[1])) continue;
-                    for (int a = 0; a < 3; ++a) c[j / 2][a] += 0.5 * (b[2 * a] + b[2 * a + 1]);
-                    have[j / 2]++;
+                    const int h = j < RT_WIDE / 2 ? 0 : 1;
+                    for (int a = 0; a < 3; ++a) ctr[h][a] += 0.5 * (b[2 * a] + b[2 * a + 1]);
+                    have[h]++;
                 }
-                uint32_t axis = 0;
                 if (have[0] && have[1]) {
                     double best = -1.0;
                     for (int a = 0; a < 3; ++a) {
-                        const double sep = std::fabs(c[0][a] / have[0] - c[1][a] / have[1]);
+                        const double sep = std::fabs(ctr[0][a] / have[0] - ctr[1][a] / have[1]);
                         if (sep > best) { best = sep; axis = (uint32_t)a; }
                     }
-                    if (c[0][axis] / have[0] < c[1][axis] / have[1]) axis |= 4u;  // children 0, 1 are the LOWER ones here
+                    if (ctr[0][axis] / have[0] < ctr[1][axis] / have[1]) axis |= 4u;  // the first half is the LOWER one here
                 }
-                reinterpret_cast<uint32_t*>(rec)[12] = axis;
             }
+            uint32_t kind = 0, first = 0;
+            unsigned long long counts = 0ull;
+            if (k == 1) {  // the items: consecutive runs of one array of primitives, the used slots first
+                bool ended = false;
+                uint32_t next = 0;
+                for (uint32_t j = 0; j < RT_WIDE; ++j) {
+                    const uint32_t f = desc[2 * (RT_WIDE * g + j)], kc = desc[2 * (RT_WIDE * g + j) + 1];
+                    const uint32_t cnt = kc & 0xFFFFFFu;
+                    if (cnt == 0) { ended = true; continue; }
+                    if (ended || cnt > 255u) return false;
+                    if (j == 0) { kind = kc >> 24; first = f; next = f; }
+                    if ((kc >> 24) != kind || f != next) return false;
+                    next = f + cnt;
+                    counts |= (unsigned long long)cnt << (8u * j);
+                }
+            }
+            words[24] = first;
+            words[25] = kind | axis << 8;
+            words[26] = (uint32_t)counts;
+            words[27] = (uint32_t)(counts >> 32);
         }
     }
     return true;
@@ -292,19 +316,26 @@ struct WLane {
     double tmin, tmax;        // the ray's interval at the top level
     double s, e;              // inside a leaf: the interval its box narrowed that to, e shortened by every hit since
     Best best;
-    unsigned long long pending;  // bits 4k .. 4k + 3: children of the level-k node above the cursor still to be visited
-    uint32_t rev;                // fast mode: bit k set = the level-k node's children are taken from 3 down to 0
-    uint32_t slot, level;     // the node to look at next is (level, slot >> 2 level)
+    unsigned long long pending;  // bits 8k .. 8k + 7: children of the level-k node above the cursor still to be visited
+    uint32_t rev;                // fast mode: bit k set = the level-k node's children are taken from 7 down to 0
+    uint32_t slot, level;     // the node to look at next is (level, slot >> 3 level)
     uint32_t k, kend, kind;   // run in progress; kind bit 9: the leaf's box has yet to narrow the interval (lambda = 0)
-    uint32_t d0x, d0y, d1x, d1y, d2x, d2y, d3x, d3y;  // the items of the level-1 node above the cursor
+    uint32_t item_first, item_kind;  // the items of the level-1 node above the cursor: first primitive, kind,
+    unsigned long long item_counts;  // primitives per item (a byte each)
     uint32_t state;
 };
-RT_HD bool wide_box(uint32_t wx, uint32_t wy, uint32_t wz, const WLane& ln, float s, float e) {
+// Whether the ray's interval (s, e) may touch a child box, given as three words of two u16 grid values (x, y, z:
+// start | end << 16).  Nothing depends on the exact outcome -- a box is passed over only when this says it cannot be
+// touched -- so the test is written for speed: f32, one fused multiply-add per plane, no branches; the boxes are a grid
+// step wider than the geometry on every side for it (see wide_begin), and the caller rounds s down and e up.  A NaN
+// (0 * inf: a ray in a box's plane) drops out of min / max, which leaves that axis undecided: the box counts as touched.
+RT_HD bool wide_box(uint32_t wx, uint32_t wy, uint32_t wz, const WLane& ln, float s, float e, float& entry) {
     const float x0 = fmaf((float)(wx & 0xFFFFu), ln.ax, ln.bx), x1 = fmaf((float)(wx >> 16), ln.ax, ln.bx);
     const float y0 = fmaf((float)(wy & 0xFFFFu), ln.ay, ln.by), y1 = fmaf((float)(wy >> 16), ln.ay, ln.by);
     const float z0 = fmaf((float)(wz & 0xFFFFu), ln.az, ln.bz), z1 = fmaf((float)(wz >> 16), ln.az, ln.bz);
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), s));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), e));
+    entry = tn;
     return !(tf <= tn);
 }
 RT_HD void wide_begin(WLane& ln, const DScene& S, const DWide& W, const Ray& world, double tmin, double tmax, Best best) {
@@ -328,22 +359,22 @@ RT_HD void wide_begin(WLane& ln, const DScene& S, const DWide& W, const Ray& wor
     ln.rev = 0u;
     ln.slot = 0u; ln.level = W.K;
     ln.k = ln.kend = 0u; ln.kind = 0u;
-    ln.d0x = ln.d0y = ln.d1x = ln.d1y = ln.d2x = ln.d2y = ln.d3x = ln.d3y = 0u;
+    ln.item_first = 0u; ln.item_kind = 0u; ln.item_counts = 0ull;
     ln.state = RT_W_NODE;
 }
 // Moves the cursor to child j of the level-k node above it: a node of level k - 1, or (k = 1) an item, whose run of
 // primitives starts.  Written without branches and with every field assigned on every path: fields stored in one
 // branch only end up addressed through a selected pointer, and the whole lane state then lives in scratch memory.
 RT_HD void wide_goto(WLane& ln, const DWide& W, uint32_t k, uint32_t j) {
-    ln.slot = ((ln.slot >> (2u * k)) << (2u * k)) | (j << (2u * (k - 1u)));
-    const uint32_t m0 = j == 0u ? 0xFFFFFFFFu : 0u, m1 = j == 1u ? 0xFFFFFFFFu : 0u, m2 = j == 2u ? 0xFFFFFFFFu : 0u,
-                   m3 = j == 3u ? 0xFFFFFFFFu : 0u;
-    const uint32_t first = (ln.d0x & m0) | (ln.d1x & m1) | (ln.d2x & m2) | (ln.d3x & m3);
-    const uint32_t kc = (ln.d0y & m0) | (ln.d1y & m1) | (ln.d2y & m2) | (ln.d3y & m3);
+    ln.slot = ((ln.slot >> (RT_WIDE_LOG * k)) << (RT_WIDE_LOG * k)) | (j << (RT_WIDE_LOG * (k - 1u)));
+    // item j's run: the primitives after those of items 0 .. j - 1 (the bytes below byte j summed by one multiply)
+    const unsigned long long below = ln.item_counts & ((1ull << (8u * j)) - 1ull);
+    const uint32_t first = ln.item_first + (uint32_t)((below * 0x0101010101010101ull) >> 56);
+    const uint32_t count = (uint32_t)(ln.item_counts >> (8u * j)) & 0xFFu;
     const bool item = k == 1u;
-    ln.kind = item ? ((kc >> 24) | (W.lambda == 0u ? 0x200u : 0u)) : ln.kind;
+    ln.kind = item ? ((ln.item_kind & 0xFFu) | (W.lambda == 0u ? 0x200u : 0u)) : ln.kind;
     ln.k = item ? first : ln.k;
-    ln.kend = item ? first + (kc & 0xFFFFFFu) : ln.kend;
+    ln.kend = item ? first + count : ln.kend;
     ln.level = k - 1u;
     ln.state = item ? RT_W_PRIM : RT_W_NODE;
 }
@@ -354,41 +385,44 @@ RT_HD uint32_t ctz64(unsigned long long x) {
     return (uint32_t)__builtin_ctzll(x);
 #endif
 }
+RT_HD uint32_t top_bit8(uint32_t g) {  // index of the highest set bit of g in 1..255
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 31u - (uint32_t)__clz((int)g);
+#else
+    return 31u - (uint32_t)__builtin_clz(g);
+#endif
+}
 // On to the nearest child still to be visited of the nodes above the cursor, or done.
 RT_HD void wide_ascend(WLane& ln, const DWide& W) {
     const bool none = ln.pending == 0ull;
-    const uint32_t p = none ? 4u : ctz64(ln.pending);
-    const uint32_t k = p >> 2;
-    uint32_t j = p & 3u;
-    if (W.fast) {  // the farthest-numbered child first where the node's order is reversed
-        const uint32_t g = (uint32_t)(ln.pending >> (4u * k)) & 15u;
-        const uint32_t top = g >= 8u ? 3u : (g >= 4u ? 2u : (g >= 2u ? 1u : 0u));
-        j = ((ln.rev >> k) & 1u) != 0u && !none ? top : j;
+    const uint32_t p = none ? 8u : ctz64(ln.pending);
+    const uint32_t k = p >> 3;
+    uint32_t j = p & 7u;
+    if (W.fast) {  // the highest-numbered child first where the node's order is reversed
+        const uint32_t g = (uint32_t)(ln.pending >> (8u * k)) & 0xFFu;
+        j = (((ln.rev >> k) & 1u) != 0u && !none) ? top_bit8(g | 1u) : j;
     }
-    ln.pending &= ~((none ? 0ull : 1ull) << (4u * k + j));
+    ln.pending &= ~((none ? 0ull : 1ull) << (8u * k + j));
     wide_goto(ln, W, k, j);
     ln.state = none ? RT_W_DONE : ln.state;
 }
-// Whether the ray's interval (s, e) may touch a child box, given as three words of two u16 grid values (x, y, z:
-// start | end << 16).  Nothing depends on the exact outcome -- a box is passed over only when this says it cannot be
-// touched -- so the test is written for speed: f32, one fused multiply-add per plane, no branches; the boxes are a grid
-// step wider than the geometry on every side for it (see wide_begin), and the caller rounds s down and e up.  A NaN
-// (0 * inf: a ray in a box's plane) drops out of min / max, which leaves that axis undecided: the box counts as touched.
-RT_HD bool wide_box(uint32_t wx, uint32_t wy, uint32_t wz, const WLane& ln, float s, float e);
-// One node for a lane in RT_W_NODE: the reference's narrowing when the node is a leaf's, then its four child boxes.
-RT_HD void wide_node_step(const DWide& W, WLane& ln) {
+// One node for a lane in RT_W_NODE: the reference's narrowing when the node is a leaf's, then its eight child boxes.
+struct WNodeRec { uint4 q0, q1, q2, q3, q4, q5, tail; };  // the first 112 bytes of a node
+RT_HD uint32_t wide_cursor_node(const DWide& W, const WLane& ln) { return wide_node_index(W.K, ln.level, ln.slot >> (RT_WIDE_LOG * ln.level)); }
+RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec) {
     const uint32_t k = ln.level;
-    const uint4* rp = W.nodes + 4u * wide_node_index(W.K, k, ln.slot >> (2u * k));
-    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    const uint4 q0 = rec.q0, q1 = rec.q1, q2 = rec.q2, q3 = rec.q3, q4 = rec.q4, q5 = rec.q5;
     uint32_t axis = 0u;
-    if (W.fast) axis = rp[3].x;
-    if (k == 1u) {
-        const uint4* ip = W.items + 2u * (ln.slot >> 2);
-        const uint4 a = ip[0], b = ip[1];
-        ln.d0x = a.x; ln.d0y = a.y; ln.d1x = a.z; ln.d1y = a.w; ln.d2x = b.x; ln.d2y = b.y; ln.d3x = b.z; ln.d3y = b.w;
+    if (W.fast || k == 1u) {
+        const uint4 tail = rec.tail;
+        axis = (tail.y >> 8) & 7u;
+        // (assigned on every path, see wide_goto)
+        ln.item_first = k == 1u ? tail.x : ln.item_first;
+        ln.item_kind = k == 1u ? tail.y : ln.item_kind;
+        ln.item_counts = k == 1u ? ((unsigned long long)tail.w << 32 | tail.z) : ln.item_counts;
     }
     if (W.lambda != 0u && k == W.lambda) {  // BVHNode::hit's box test for the leaf (bvh.rs:31-37)
-        const double2* rb = W.refbox + 3u * (ln.slot >> (2u * W.lambda));
+        const double2* rb = W.refbox + 3u * (ln.slot >> (RT_WIDE_LOG * W.lambda));
         const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
 #if defined(__HIP_DEVICE_COMPILE__)
         // keeps the compiler from sinking the loads into the slab test's branches, where each would wait on its own
@@ -403,11 +437,20 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln) {
     float cs = (float)ds, ce = (float)de;
     cs = fmaf(-fabsf(cs), 1.1920929e-7f, cs);  // not above ds, not below de (an infinity stays one)
     ce = fmaf(fabsf(ce), 1.1920929e-7f, ce);
-    uint32_t m = 0u;
-    if (wide_box(q0.x, q0.y, q0.z, ln, cs, ce)) m |= 1u;
-    if (wide_box(q0.w, q1.x, q1.y, ln, cs, ce)) m |= 2u;
-    if (wide_box(q1.z, q1.w, q2.x, ln, cs, ce)) m |= 4u;
-    if (wide_box(q2.y, q2.z, q2.w, ln, cs, ce)) m |= 8u;
+    uint32_t m = 0u, nearest = 0u;
+    float t, least = __builtin_inff();
+    // (the child whose box the ray enters first, for the fast mode: a running minimum, the lowest child on ties)
+#define RT_WIDE_CHILD(J, WX, WY, WZ) \
+    if (wide_box(WX, WY, WZ, ln, cs, ce, t)) { m |= 1u << J; const bool nearer = t < least; nearest = nearer ? J : nearest; least = nearer ? t : least; }
+    RT_WIDE_CHILD(0u, q0.x, q0.y, q0.z)
+    RT_WIDE_CHILD(1u, q0.w, q1.x, q1.y)
+    RT_WIDE_CHILD(2u, q1.z, q1.w, q2.x)
+    RT_WIDE_CHILD(3u, q2.y, q2.z, q2.w)
+    RT_WIDE_CHILD(4u, q3.x, q3.y, q3.z)
+    RT_WIDE_CHILD(5u, q3.w, q4.x, q4.y)
+    RT_WIDE_CHILD(6u, q4.z, q4.w, q5.x)
+    RT_WIDE_CHILD(7u, q5.y, q5.z, q5.w)
+#undef RT_WIDE_CHILD
     if (m == 0u) { wide_ascend(ln, W); return; }
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t j = (uint32_t)(__ffs((int)m) - 1);
@@ -415,23 +458,30 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln) {
     uint32_t j = (uint32_t)__builtin_ctz(m);
 #endif
     if (W.fast) {
-        // Nearest first: children 0, 1 lie beyond (axis bit 2: before) children 2, 3 along `axis`, so a ray that runs
-        // up that axis meets 2, 3 first.  Whatever the order, every child whose box the interval can touch is visited
-        // unless a closer hit has shortened the interval meanwhile; only hits at exactly equal parameters can come out
-        // differently from the reference's order.
+        // Nearest first: the child whose box the ray enters first now; the others later from the near end of the node,
+        // judged by one axis: children 0..3 lie beyond (axis bit 2: before) children 4..7 along `axis`, so a ray that
+        // runs up that axis meets 4..7 first.  Whatever the order, every child whose box the interval can touch is
+        // visited unless a closer hit has shortened the interval meanwhile; only hits at exactly equal parameters can
+        // come out differently from the reference's order.
         // (comparisons first, then the choice between their results: a choice between the fields themselves would be
         // turned into a load through a selected address, and the lane state would live in scratch memory)
         const bool px = ln.cur.d.x > 0.0, py = ln.cur.d.y > 0.0, pz = ln.cur.d.z > 0.0;
         const uint32_t a = axis & 3u;
         const bool up = (a == 0u && px) || (a == 1u && py) || (a == 2u && pz);
         const bool reversed = ((axis & 4u) != 0u) != up;
-        const uint32_t top = m >= 8u ? 3u : (m >= 4u ? 2u : (m >= 2u ? 1u : 0u));
-        j = reversed ? top : j;
+        j = least < __builtin_inff() ? nearest : (reversed ? top_bit8(m) : j);  // (every entry a NaN: any order)
         ln.rev = (ln.rev & ~(1u << k)) | ((reversed ? 1u : 0u) << k);
     }
     m &= ~(1u << j);
-    ln.pending |= (unsigned long long)m << (4u * k);
+    ln.pending |= (unsigned long long)m << (8u * k);
     wide_goto(ln, W, k, j);
+}
+// The same with the node read by the lane itself.
+RT_HD void wide_node_step(const DWide& W, WLane& ln) {
+    const uint4* rp = W.nodes + 8u * wide_cursor_node(W, ln);
+    WNodeRec rec;
+    rec.q0 = rp[0]; rec.q1 = rp[1]; rec.q2 = rp[2]; rec.q3 = rp[3]; rec.q4 = rp[4]; rec.q5 = rp[5]; rec.tail = rp[6];
+    wide_node_step(W, ln, rec);
 }
 // The next primitives of the run in progress for a lane in RT_W_PRIM (lane_prim_tests: two planar primitives or four
 // spheres per step).

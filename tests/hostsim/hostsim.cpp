@@ -114,7 +114,6 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
                     DWide W;
                     W.nodes = reinterpret_cast<const uint4*>(wb.nodes.data());
                     W.refbox = reinterpret_cast<const double2*>(wb.refbox.data());
-                    W.items = reinterpret_cast<const uint4*>(wb.items.data());
                     for (int ax = 0; ax < 3; ++ax) { W.base[ax] = wb.base[ax]; W.step[ax] = wb.step[ax]; }
                     W.K = wb.K; W.lambda = wb.lambda; W.chain = wb.chain; W.fast = (uint32_t)use_fast;
                     WLane wl;
