@@ -286,7 +286,7 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
             out["roofline_hbm"] = hbm
     else:
         out["roofline"] = None
-    if stats and not stats[0]["lockstep"] and world == 1:
+    if stats and not stats[0]["lockstep"] and world == 1 and not args.no_fast_report:
         out["fast_bvh"] = fast_bvh_report(scene, cam, spec, film, spp, out["value"])
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(key, width)
@@ -309,6 +309,8 @@ def main():
     ap.add_argument("--fast-bvh", action="store_true", help="RT_FLAG_FAST_BVH for the timed steps (invalidates the metric: "
                     "ties between primitives are not decided as the reference decides them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-report", action="store_true", help="skip the untimed RT_FLAG_FAST_BVH comparison renders "
+                    "(profiling runs: their launches would be counted with the timed ones)")
     ap.add_argument("--no-also", action="store_true", help="skip the BVH workloads timed after the headline one")
     ap.add_argument("--also-c5-spp", type=int, default=1000, help="samples per pixel of the C5 entry under \"also\"")
     ap.add_argument("--whole-paths", action="store_true", help="RT_FLAG_WHOLE_PATHS: one kernel per batch (BVH-free scenes)")

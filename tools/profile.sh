@@ -6,7 +6,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="python3 $root/bench.py --config $cfg --spp $spp --steps ${STEPS:-1} --warmup ${WARMUP:-0} --no-cpu-baseline --no-also"
+cmd="python3 $root/bench.py --config $cfg --spp $spp --steps ${STEPS:-1} --warmup ${WARMUP:-0} --no-cpu-baseline --no-also --no-fast-report"
 cd /tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $cmd > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 i=0
