@@ -745,14 +745,18 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
 // its latency and little else -- dozens of launches of some tens of microseconds.  This kernel takes the rays that
 // are left, one per lane, and follows each path to its end: the same material code and shared rejection loop as the
 // bounce and shade kernels, bounce after bounce, no queue written; the walk is the lockstep one for trees without BVH
-// entries and the plain per-lane walk (the one k_trace_samples uses) for trees with them -- with so few rays it is
-// the length of the longest path that counts, not how well the lanes are used.  counters[0] += rays traced,
-// counters[1] = max(iteration index after the last bounce of any path).
+// entries; for trees with them each lane goes through the stretches of the top level as the traverse launches do, one
+// after the other, a wide tree (rt_wide.h) by its own walk and everything else by the plain per-lane walk (with so few
+// rays it is the length of the longest path that counts, not how well the lanes are used -- but the wide tree's
+// boxes are tight where the reference's reach the origin, and a deep path through a large mesh is many times shorter
+// there).  n_stretch = 0: the plain walk over the whole tree.  counters[0] += rays traced, counters[1] = max(iteration
+// index after the last bounce of any path).
 #define RT_FINISH_MAX (1u << 17)  // rays in flight (upper bound) from which the tail is taken in one launch
 template <bool LOCKSTEP, int MEDIA, bool PLAIN>
 __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
     DScene S, uint64_t seed, Segs segs, Queue q, double* lum_r, double* lum_g, double* lum_b, double bgr, double bgg,
-    double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters) {
+    double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters, const Stretch* stretches,
+    uint32_t n_stretch, const DWide* wides, uint32_t fast) {
     uint32_t n;
     const uint32_t idx = seg_slot(segs, n);
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
@@ -780,7 +784,31 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
             rays++;
             last = it + 1u;
             RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32); rp.pixel = pix; rp.sample = smp; rp.ctr = ctr;
-            const Best b = closest_hit<false, LOCKSTEP, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
+            Best b;
+            bool walked = false;
+            if constexpr (!LOCKSTEP) {
+                if (n_stretch != 0u) {
+                    walked = true;
+                    b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
+                    for (uint32_t si = 0; si < n_stretch; ++si) {
+                        const Stretch st = stretches[si];
+                        if (st.kind == RT_STRETCH_WIDE) {
+                            DWide W = wides[st.wide];
+                            W.fast = fast;
+                            WLane wl;
+                            wide_begin(wl, S, W, w, 0.001, RT_INF, b);
+                            while (wl.state != RT_W_DONE) {
+                                if (wl.state == RT_W_NODE) wide_node_step(W, wl);
+                                else wide_prim_step<false>(S, W, wl, tally);
+                            }
+                            b = wl.best;
+                        } else {
+                            b = closest_hit_range<false, false, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally, st.first, st.end, b);
+                        }
+                    }
+                }
+            }
+            if (!walked) b = closest_hit<false, LOCKSTEP, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
             ctr = rp.ctr;
             if (b.ref == RT_NO_HIT) {
                 lum = beta * mk(bgr, bgg, bgb);
@@ -943,6 +971,8 @@ struct rt_scene {
     std::vector<Stretch> stretches;
     std::vector<WideBvh> wide;     // the eight-wide trees of the BVH entries that take one (rt_wide.h)
     std::vector<DWide> d_wide;     // on the device
+    const Stretch* dev_stretches = nullptr;  // the two vectors above in device memory, for the tail kernel
+    const DWide* dev_wides = nullptr;
     GateInfo gate;                 // one gate per wide tree (the first RT_MAX_GATES of them): wide tree w has gate w
     const GateInfo* d_gate = nullptr;
     int media_mode = RT_MEDIA_NONE;  // RT_MEDIA_FLAT when every medium's boundary is plain primitives, else RT_MEDIA_ANY
@@ -1299,6 +1329,8 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
         dw.K = w.K; dw.lambda = w.lambda; dw.chain = w.chain; dw.fast = 0u;
         s->d_wide.push_back(dw);
     }
+    if ((rc = upload(s, s->stretches, &s->dev_stretches))) return rc;
+    if ((rc = upload(s, s->d_wide, &s->dev_wides))) return rc;
     {
         DScene h;  // host pointers, for chain_map
         std::memset(&h, 0, sizeof h);
@@ -1831,7 +1863,9 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));
                 HIP_TRY(hipEventRecord(s->ev[1], sm));
 #define FINISH_ARGS d, o->seed, segs, qin, s->lum_r, s->lum_g, s->lum_b, o->background[0], o->background[1], \
-                    o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8)
+                    o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8), s->dev_stretches, \
+                    (uint32_t)((lockstep || nocull) ? 0u : s->stretches.size()), s->dev_wides, \
+                    (uint32_t)(((o->flags & RT_FLAG_FAST_BVH) || s->fast_bvh) ? 1u : 0u)
 #define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(fblock), \
                                             levels_lds(s, fblock), sm, FINISH_ARGS)
                 if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
