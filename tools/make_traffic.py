@@ -4,7 +4,7 @@ the PMC summaries tools/profile.sh leaves under gpurun_out/prof_<tag>/ (copied t
 
 Per workload, for the dominant kernel bench.py names (for trees with BVH entries: all launches of a bounce's traverse
 phase together):
-  hbm_bytes_per_ray = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / rays of the profiled run's timed steps.  rocprofv3 reports
+  hbm_bytes_per_ray = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / rays of the profiled run (warm-up steps included).  rocprofv3 reports
       both counters in KiB, and on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so the read side is
       doubled.  The two counters come from separate --pmc passes of the same command.
   valu_issue: SQ_INSTS_VALU x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz x the kernel's summed duration): the share of
@@ -51,7 +51,8 @@ def main():
         if not names or "FETCH_SIZE" not in agg:
             print(f"{cfg}: no counters for {wanted}", file=sys.stderr)
             continue
-        rays = roof["rays_per_launch"] * roof["launches"]
+        # the counters cover the warm-up steps of the profiled command as well as the timed ones
+        rays = roof["rays_per_launch"] * roof["launches"] * (line["steps"] + line["warmup"]) / max(line["steps"], 1)
         entry = {"kernel": roof["kernel"], "profiled_kernels": sorted(names), "profiled_rays": rays, "profiled_kernel_ms": ms,
                  "hbm_bytes_per_ray": (2.0 * agg["FETCH_SIZE"] + agg["WRITE_SIZE"]) * 1024.0 / rays,
                  "source": os.path.relpath(summary, ROOT)}
