@@ -362,10 +362,11 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide
         if (mask != 0ull && (__popcll(mask) >= a.thr_fetch || n_node + n_prim == 0)) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
             if (PROF) { pc[3]++; pc[6] += (unsigned long long)__popcll(mask); }
-            if (need && idx != 0xFFFFFFFFu) {
-                a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
-                idx = 0xFFFFFFFFu;
-            }
+            // The finished ray's result is stored after the next ray has been read: loads and stores of a wavefront
+            // complete in the order issued, and the new ray's loads would otherwise wait for the stores' round trip too.
+            const uint32_t done_idx = need ? idx : 0xFFFFFFFFu;
+            const Best done_best = ln.best;
+            if (need) idx = 0xFFFFFFFFu;
             if (!exhausted) {
                 if (pool_next == pool_end) {
                     const int leader = __ffsll((long long)mask) - 1;
@@ -389,6 +390,9 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide
                     const uint32_t want = pool_next + (uint32_t)__popcll(mask);
                     pool_next = want < pool_end ? want : pool_end;
                 }
+            }
+            if (done_idx != 0xFFFFFFFFu) {
+                a.hb.t[done_idx] = done_best.t; a.hb.ref[done_idx] = done_best.ref; a.hb.chain[done_idx] = done_best.chain;
             }
             if (exhausted && __ballot(ln.state != RT_W_DONE) == 0ull) break;
             n_node = __popcll(__ballot(ln.state == RT_W_NODE));

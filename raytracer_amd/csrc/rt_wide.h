@@ -11,13 +11,16 @@
 // the tree otherwise; such a tree keeps the entry-by-entry walk of rt_core.h.
 //
 // The tree built here: the leaves in visiting order, each cut into items (a pair of triangles or quads with the box
-// around their corners, a whole run of spheres, one box-shaped list of quads, ...), every leaf padded to 8^lambda
-// item slots.  Above the items sits a complete 8-ary tree in heap order: node (k, g) covers slots
-// [g * 8^k, (g + 1) * 8^k) and holds the boxes of its eight children on a 16-bit grid, rounded outwards (none of
-// them narrows anything: a subtree is passed over only when the ray's interval cannot touch the geometry below it).
-// A lane walks it with a cursor that only moves forward, as the reference does, and remembers which children of the
-// nodes above it are still to be visited in eight bits per level of one 64-bit register.  The level-lambda node of a
-// leaf is where the leaf's own f64 box does the reference's narrowing (for lambda = 0 the first primitive step does).
+// around their corners, a whole run of spheres, one box-shaped list of quads, ...) that take consecutive item slots;
+// a leaf of several items starts on a multiple of eight slots, and so does a change of kind inside it.  Above the
+// items sits a complete 8-ary tree in heap order: node (k, g) covers slots [g * 8^k, (g + 1) * 8^k) and holds the
+// boxes of its eight children on a 16-bit grid, rounded outwards (none of them narrows anything: a subtree is passed
+// over only when the ray's interval cannot touch the geometry below it).  A lane walks it with a cursor that only
+// moves forward, as the reference does, and remembers which children of the nodes above it are still to be visited
+// in eight bits per level of one 64-bit register.  The reference's narrowing by the leaf's own f64 box happens at the
+// level-1 nodes of the leaf (lambda = 1; every one of them does it: the narrowed interval is a function of the box and
+// of the closest hit so far, so doing it again gives what carrying it along would) or, where every leaf is a single
+// item and eight leaves share a level-1 node (lambda = 0), in the item's first primitive step.
 #pragma once
 
 #include "rt_core.h"
@@ -41,10 +44,10 @@ struct DWide {               // as the kernels see it
                              // items' primitive kind, bits 8..10 the axis along which children 0..3 lie beyond (bit 10:
                              // before) children 4..7 | the eight items' primitive counts, a byte each (two words).  The
                              // items of a level-1 node are consecutive runs of one array of primitives.
-    const double2* refbox;   // per leaf: the reference's box, 3 x (start, end)
+    const double2* refbox;   // per level-lambda node: the reference's box of its leaf, 3 x (start, end)
     double base[3], step[3]; // the grid
     uint32_t K;              // the root is node (K, 0)
-    uint32_t lambda;         // a leaf covers 8^lambda item slots
+    uint32_t lambda;         // 1: the level-1 nodes belong to one leaf each and narrow by its box; 0: the items do
     uint32_t chain;          // the instance chain the whole tree lives in
     uint32_t fast;           // 1: children are visited nearest first (see wide_node_step); results then differ from the
                              // reference's where two primitives are hit at exactly the same parameter
@@ -57,7 +60,7 @@ RT_HD uint32_t wide_node_index(uint32_t K, uint32_t k, uint32_t g) {
 struct WideBvh {
     uint32_t entry = 0, end = 0, chain = 0, K = 0, lambda = 0, leaves = 0;
     std::vector<uint32_t> nodes;  // 32 words per node
-    std::vector<double> refbox;   // 6 per leaf
+    std::vector<double> refbox;   // 6 per level-lambda node
     double base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
     double bounds[6] = {0, 0, 0, 0, 0, 0};  // of everything below the entry (x, y, z: start, end), in its chain
 };
@@ -147,22 +150,34 @@ inline bool collect(Ctx& c, uint32_t e, int parent, int depth) {
 }
 }  // namespace wide_detail
 
-// Builds the wide tree for the top-level BVH entry `root` (level 0).  False when the subtree is not of the shape
-// described above; the caller then walks it entry by entry.
-inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, const double* boxes, const double* spheres,
-                       const double* quads, const double* tris, WideBvh& out) {
-    using namespace wide_detail;
-    if (root >= n_nodes || nodes[root].kind != RT_NODE_BVH || nodes[root].level != 0) return false;
-    Ctx c; c.nodes = nodes; c.n = n_nodes; c.boxes = boxes; c.spheres = spheres; c.quads = quads; c.tris = tris;
-    c.chain = nodes[root].chain;
-    if (!collect(c, root, -1, 0) || c.leaves.empty()) return false;
-    size_t most = 0;
-    for (const Leaf& l : c.leaves) most = std::max(most, l.items.size());
-    uint32_t lambda = 0;
-    while ((1ull << (RT_WIDE_LOG * lambda)) < most) ++lambda;
-    if (lambda > 2) return false;
-    const uint64_t slots = (uint64_t)c.leaves.size() << (RT_WIDE_LOG * lambda);
-    uint32_t K = std::max(1u, lambda);
+namespace wide_detail {
+// The tree over the collected leaves for one choice of lambda; false when a level-1 node would hold items of different
+// kinds or of runs that are not consecutive (possible for lambda = 0 only), or when the tree would be too deep.
+inline bool build_wide_slots(const Ctx& c, const rt_node* nodes, uint32_t root, const double* boxes, uint32_t lambda, WideBvh& out) {
+    std::vector<std::vector<uint32_t>> slot_of(c.leaves.size());
+    std::vector<uint32_t> box_of;  // per level-lambda node: the leaf whose box narrows the interval there
+    uint64_t slots = 0;
+    for (size_t l = 0; l < c.leaves.size(); ++l) {
+        const Leaf& leaf = c.leaves[l];
+        slot_of[l].resize(leaf.items.size());
+        if (lambda == 0u) {
+            if (leaf.items.size() != 1) return false;
+            slot_of[l][0] = (uint32_t)slots++;
+            box_of.push_back((uint32_t)l);
+            continue;
+        }
+        for (size_t i = 0; i < leaf.items.size(); ++i) {
+            const Item& it = leaf.items[i];
+            if (i > 0) {
+                const Item& before = leaf.items[i - 1];
+                if (it.kind != before.kind || it.first != before.first + before.count) slots = (slots + RT_WIDE - 1) / RT_WIDE * RT_WIDE;
+            }
+            slot_of[l][i] = (uint32_t)slots++;
+        }
+        slots = (slots + RT_WIDE - 1) / RT_WIDE * RT_WIDE;
+        while (box_of.size() < slots / RT_WIDE) box_of.push_back((uint32_t)l);
+    }
+    uint32_t K = 1;
     while ((1ull << (RT_WIDE_LOG * K)) < slots) ++K;
     if (K > RT_WIDE_MAX_K) return false;  // 2 M item slots
     out.entry = root; out.end = nodes[root].skip; out.chain = c.chain; out.K = K; out.lambda = lambda;
@@ -174,12 +189,12 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
     lv[0].assign(6 * width, 0.0);
     for (size_t i = 0; i < width; ++i) for (int a = 0; a < 3; ++a) { lv[0][6 * i + 2 * a] = inf; lv[0][6 * i + 2 * a + 1] = -inf; }
     std::vector<uint32_t> desc(2 * width, 0u);
-    out.refbox.resize(6 * c.leaves.size());
+    out.refbox.resize(6 * box_of.size());
+    for (size_t g = 0; g < box_of.size(); ++g) std::memcpy(&out.refbox[6 * g], boxes + 6 * (size_t)c.leaves[box_of[g]].box, 48);
     for (size_t l = 0; l < c.leaves.size(); ++l) {
-        std::memcpy(&out.refbox[6 * l], boxes + 6 * (size_t)c.leaves[l].box, 48);
         for (size_t i = 0; i < c.leaves[l].items.size(); ++i) {
             const Item& it = c.leaves[l].items[i];
-            const size_t slot = (l << (RT_WIDE_LOG * lambda)) + i;
+            const size_t slot = slot_of[l][i];
             std::memcpy(&lv[0][6 * slot], it.box, 48);
             desc[2 * slot] = it.first;
             desc[2 * slot + 1] = it.kind << 24 | it.count;
@@ -277,6 +292,26 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
     }
     return true;
 }
+}  // namespace wide_detail
+
+// Builds the wide tree for the top-level BVH entry `root` (level 0).  False when the subtree is not of the shape
+// described above; the caller then walks it entry by entry.
+inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, const double* boxes, const double* spheres,
+                       const double* quads, const double* tris, WideBvh& out) {
+    using namespace wide_detail;
+    if (root >= n_nodes || nodes[root].kind != RT_NODE_BVH || nodes[root].level != 0) return false;
+    Ctx c; c.nodes = nodes; c.n = n_nodes; c.boxes = boxes; c.spheres = spheres; c.quads = quads; c.tris = tris;
+    c.chain = nodes[root].chain;
+    if (!collect(c, root, -1, 0) || c.leaves.empty()) return false;
+    size_t most = 0;
+    for (const Leaf& l : c.leaves) most = std::max(most, l.items.size());
+    // lambda = 0: every leaf is one item, eight leaves to a level-1 node.  lambda = 1: a leaf is one or more level-1 nodes
+    // of its own (each of them does the leaf's narrowing: the interval depends on the box and the closest hit so far
+    // alone); a new one starts wherever the items change kind or stop being consecutive runs of their array.
+    if (most <= 1 && build_wide_slots(c, nodes, root, boxes, 0u, out)) return true;
+    return build_wide_slots(c, nodes, root, boxes, 1u, out);
+}
+
 
 // The stretches of top-level entries a tree with BVH entries is walked in, one launch each, the closest hit so far
 // travelling from one to the next: entries with no BVH entry below them (every ray does the same work there) together

@@ -131,9 +131,9 @@ def test_wide_tree_over_mixed_leaves_and_fallback_for_other_trees():
     L.sim_set_walk_mode(3)
     try:
         got = sim.intersect(o, d, 0.001, np.inf, rng3)
-        # the triangle BVH only: not the one over instances, nor the one whose leaves mix kinds of primitives (the items
-        # under one level-1 node of a wide tree are runs of ONE array); those keep the entry-by-entry walk
-        assert L.sim_wide_stretches() == 1
+        # the mixed BVH (a leaf's items of another kind start a level-1 node of their own) and the triangle BVH; the
+        # one over instances keeps the entry-by-entry walk
+        assert L.sim_wide_stretches() == 2
     finally:
         L.sim_set_walk_mode(0)
     assert_hits_equal(got, want, exact=True, what="mixed scene")
