@@ -269,12 +269,16 @@ int rt_render_device(const rt_scene* s, const rt_camera* cam, const rt_render_op
 /* The same on several GPUs from ONE process: scenes[r] is the same scene committed to device r (rt_scene_commit
  * with different devices; the same device may appear more than once).  The samples [spp_begin, spp_begin +
  * spp_count) are split into n contiguous shards (the remainder goes to the low ranks, unlike camera.rs:324, which
- * drops it), every shard is rendered on its device by a host thread of its own, and the shard films are brought to
- * scenes[0]'s device (peer copies) and added in rank order; film_rgb is a host buffer.  stats (nullable) holds
- * sums over the shards, times being the slowest shard's.  The multi-process equivalent -- one process per GPU and
- * an all-reduce of rt_render_device's film -- needs no call of its own. */
+ * drops it), every shard is rendered on its device by a host thread of its own, and the shard films are summed on
+ * scenes[0]'s device: with one RCCL reduce when every scene has a device of its own (librccl is loaded at the first
+ * such call; the sum's association is then RCCL's), else -- the same device more than once, or no RCCL to load, or
+ * RT_MULTI_RCCL=0 in the environment -- by peer copies, added in rank order.  film_rgb is a host buffer.  stats
+ * (nullable) holds sums over the shards, times being the slowest shard's.  The multi-process equivalent -- one
+ * process per GPU and an all-reduce of rt_render_device's film -- needs no call of its own. */
 int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* opts,
                     double* film_rgb, rt_stats* stats);
+/* How many of this process's rt_render_multi calls had their films summed by RCCL (diagnostic). */
+uint64_t rt_multi_rccl_reductions(void);
 
 /* Per-sample radiance of chosen (pixel, sample) pairs: get_ray + ray_color for each (camera.rs:258-264).
  * radiance3 has 3 f64 per pair; nrays (nullable) the number of world.hit calls of each path. */

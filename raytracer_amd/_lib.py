@@ -74,7 +74,7 @@ RT_AMD_SYMBOLS = [
     "rt_scene_set_triangles", "rt_scene_set_quadrics", "rt_scene_set_media", "rt_scene_set_xforms",
     "rt_scene_set_nodes", "rt_scene_set_cull_boxes", "rt_scene_commit", "rt_intersect_batch", "rt_render", "rt_render_device",
     "rt_render_multi", "rt_trace_samples", "rt_tonemap_rgb8", "rt_debug_arith", "rt_intersect_batch_noalloc",
-    "rt_scene_set_fast_bvh",
+    "rt_scene_set_fast_bvh", "rt_multi_rccl_reductions",
 ]
 
 _amd = None
@@ -123,8 +123,10 @@ def amd():
     L.rt_debug_arith.argtypes = [i32, vp, vp, u64, vp, vp, vp, vp]
     for name in RT_AMD_SYMBOLS:
         f = getattr(L, name)
-        if name not in ("rt_scene_create", "rt_scene_destroy", "rt_last_error"):
+        if name not in ("rt_scene_create", "rt_scene_destroy", "rt_last_error", "rt_multi_rccl_reductions"):
             f.restype = i32
+    L.rt_multi_rccl_reductions.argtypes = []
+    L.rt_multi_rccl_reductions.restype = u64
     _amd = L
     return L
 

@@ -3,12 +3,16 @@
 // Wavefront path tracer for gfx950: one path per lane, path state in SoA queues in HBM, per bounce one
 // traverse+intersect launch and one shade+compact launch.  Build with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is loaded at run time (rccl())
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -2001,6 +2005,73 @@ static int rt_render_impl(const rt_scene* s_, const rt_camera* cam, const rt_ren
     return rc;
 }
 
+// RCCL for the film reduction of rt_render_multi, loaded when first needed: a host that renders on one GPU need not
+// have the library, and a process that already holds a copy (PyTorch brings its own) gets that one.
+extern "C++" {
+static std::atomic<uint64_t> g_rccl_reductions{0};
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::mutex lock;
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;  // one communicator set per list of devices, kept
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char* off = getenv("RT_MULTI_RCCL");
+        if (off && off[0] == '0') return;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+#define RCCL_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym))
+        RCCL_SYM(CommInitAll, "ncclCommInitAll"); RCCL_SYM(CommDestroy, "ncclCommDestroy"); RCCL_SYM(Reduce, "ncclReduce");
+        RCCL_SYM(GroupStart, "ncclGroupStart"); RCCL_SYM(GroupEnd, "ncclGroupEnd"); RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+        r.ok = r.CommInitAll && r.CommDestroy && r.Reduce && r.GroupStart && r.GroupEnd && r.GetErrorString;
+    });
+    return r;
+}
+// Sums the n device films into films[0] with one ncclReduce per device (root 0) in one group; the films live on the n
+// distinct devices devs[].  RT_OK, or an error with the reason set; 1 when RCCL is not to be had (the caller then
+// gathers the shards itself).
+int rccl_reduce_films(const std::vector<int>& devs, const std::vector<void*>& films, size_t count) {
+    Rccl& r = rccl();
+    if (!r.ok) return 1;
+    std::lock_guard<std::mutex> hold(r.lock);
+    auto it = r.comms.find(devs);
+    if (it == r.comms.end()) {
+        std::vector<ncclComm_t> c(devs.size());
+        const ncclResult_t e = r.CommInitAll(c.data(), (int)devs.size(), devs.data());
+        if (e != ncclSuccess) return fail(RT_ERR_DEVICE, "ncclCommInitAll: %s", r.GetErrorString(e));
+        it = r.comms.emplace(devs, c).first;
+    }
+    ncclResult_t e = r.GroupStart();
+    for (size_t k = 0; k < devs.size() && e == ncclSuccess; ++k) {
+        if (hipSetDevice(devs[k]) != hipSuccess) { (void)r.GroupEnd(); return fail(RT_ERR_DEVICE, "cannot select device %d", devs[k]); }
+        e = r.Reduce(films[k], films[0], count, ncclDouble, ncclSum, 0, it->second[k], (hipStream_t)0);
+    }
+    const ncclResult_t e2 = r.GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return fail(RT_ERR_DEVICE, "ncclReduce: %s", r.GetErrorString(e));
+    for (size_t k = 0; k < devs.size(); ++k) {
+        if (hipSetDevice(devs[k]) != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess)
+            return fail(RT_ERR_DEVICE, "waiting for the film reduction on device %d", devs[k]);
+    }
+    return RT_OK;
+}
+}  // namespace
+}  // extern "C++"
+
 static int rt_render_multi_impl(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* o,
                     double* film_rgb, rt_stats* stats) {
     if (!scenes || n < 1 || n > 64) return fail(RT_ERR_INVALID, "bad scene list");
@@ -2036,13 +2107,32 @@ static int rt_render_multi_impl(const rt_scene* const* scenes, int n, const rt_c
     rc = RT_OK;
     for (int r = 0; r < n && rc == RT_OK; ++r)
         if (sh[(size_t)r].rc != RT_OK) rc = fail(sh[(size_t)r].rc, "shard %d: %s", r, sh[(size_t)r].err.c_str());
-    // gather on the first device and add in rank order
+    // The films are summed on the first device: by RCCL (one reduce, root 0) when every scene has a device of its own,
+    // else -- several scenes on one device, or no RCCL to load -- gathered there by peer copy and added in rank order.
+    // (RT_MULTI_RCCL=0 keeps RCCL out; RT_MULTI_RCCL=force uses it for a single scene too.)
     const int dev0 = scenes[0]->device;
+    bool reduced = false;
+    if (rc == RT_OK) {
+        std::vector<int> devs;
+        std::vector<void*> films;
+        bool distinct = true;
+        for (int r = 0; r < n; ++r) {
+            for (int q = 0; q < r; ++q) distinct = distinct && scenes[q]->device != scenes[r]->device;
+            devs.push_back(scenes[r]->device);
+            films.push_back(sh[(size_t)r].film);
+        }
+        const char* mode = getenv("RT_MULTI_RCCL");
+        if (distinct && (n > 1 || (mode && std::strcmp(mode, "force") == 0))) {
+            const int e = rccl_reduce_films(devs, films, 3 * npix);
+            if (e == RT_OK) { reduced = true; g_rccl_reductions.fetch_add(1); }
+            else if (e < 0) rc = e;
+        }
+    }
     void* tmp = nullptr;
     std::vector<double> staging;
     if (rc == RT_OK && hipSetDevice(dev0) != hipSuccess) rc = fail(RT_ERR_DEVICE, "cannot select device %d", dev0);
-    if (rc == RT_OK && n > 1 && hipMalloc(&tmp, bytes) != hipSuccess) rc = fail(RT_ERR_DEVICE, "out of device memory");
-    for (int r = 1; r < n && rc == RT_OK; ++r) {
+    if (rc == RT_OK && n > 1 && !reduced && hipMalloc(&tmp, bytes) != hipSuccess) rc = fail(RT_ERR_DEVICE, "out of device memory");
+    for (int r = 1; r < n && rc == RT_OK && !reduced; ++r) {
         const int dev = scenes[r]->device;
         hipError_t e = dev == dev0 ? hipMemcpy(tmp, sh[(size_t)r].film, bytes, hipMemcpyDeviceToDevice)
                                    : hipMemcpyPeer(tmp, dev0, sh[(size_t)r].film, dev, bytes);
@@ -2252,6 +2342,7 @@ int rt_render(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o,
 int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, const rt_render_opts* o, double* film_rgb, rt_stats* stats) {
     return guarded([&]() -> int { return rt_render_multi_impl(scenes, n, cam, o, film_rgb, stats); });
 }
+uint64_t rt_multi_rccl_reductions(void) { return g_rccl_reductions.load(); }
 int rt_trace_samples(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, uint64_t n, const uint32_t* pixel, const uint32_t* sample, double* radiance3, uint32_t* nrays) {
     return guarded([&]() -> int { return rt_trace_samples_impl(s_, cam, o, n, pixel, sample, radiance3, nrays); });
 }

@@ -318,6 +318,31 @@ def test_render_multi_splits_samples_and_adds_shards_in_rank_order():
             d.close()
 
 
+def test_render_multi_reduces_the_films_with_rccl(monkeypatch):
+    """With every scene on a device of its own rt_render_multi sums the films with one RCCL reduce.  A one-GPU box has
+    one such device: RT_MULTI_RCCL=force takes a single scene through the same calls (library loaded at run time,
+    communicator, grouped reduce with root 0, stream wait), and the film must come out as rt_render gives it."""
+    from raytracer_amd import HostBuilder, _lib, camera_new, scenes
+    from raytracer_amd.scene import render_multi
+    spec = scenes.build("C2", HostBuilder(), **SMALL["C2"])
+    cam = camera_new(image_width=spec.width, **spec.camera)
+    scene = spec.builder.commit(0)
+    try:
+        whole, _ = scene.render(cam, 5, spec.max_depth, spec.background, spp_begin=1)
+        before = _lib.amd().rt_multi_rccl_reductions()
+        monkeypatch.setenv("RT_MULTI_RCCL", "force")
+        film, st = render_multi([scene], cam, 5, spec.max_depth, spec.background, spp_begin=1)
+        assert _lib.amd().rt_multi_rccl_reductions() == before + 1
+        assert np.array_equal(film, whole) and st["paths"] == 5 * cam.width * cam.height
+        film2, _ = render_multi([scene], cam, 5, spec.max_depth, spec.background, spp_begin=1)  # the communicator is kept
+        assert _lib.amd().rt_multi_rccl_reductions() == before + 2 and np.array_equal(film2, whole)
+        monkeypatch.setenv("RT_MULTI_RCCL", "1")
+        film3, _ = render_multi([scene], cam, 5, spec.max_depth, spec.background, spp_begin=1)
+        assert _lib.amd().rt_multi_rccl_reductions() == before + 2 and np.array_equal(film3, whole)
+    finally:
+        scene.close()
+
+
 def test_edge_cases_empty_inputs_and_limits(gpu_scenes):
     """What the reference does at the edges: an empty world shows the background (camera.rs:364-366 on a miss);
     depth 0 is black (camera.rs:350-352); zero samples leave the fold's start value -0.0 (point3/mod.rs:96-109);
