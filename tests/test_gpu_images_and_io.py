@@ -206,3 +206,28 @@ def test_two_renders_into_one_device_film_through_render_sharded():
         np.testing.assert_allclose(whole.cpu().numpy(), want_a + want_b, rtol=1e-12, atol=1e-12)
     finally:
         scene.close()
+
+
+def test_render_sharded_over_the_nccl_backend_with_one_rank():
+    """The multi-process route (one process per GPU, film all-reduced by RCCL through torch.distributed) with the one
+    rank a one-GPU box can hold: process group on the "nccl" backend, device film, all-reduce, barrier -- the calls
+    bench.py --gpus N makes -- and the film must be the single-process film."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.dist import render_scene_sharded, shard_range
+    hs, _ = build_pair("C4", width=64, spp=4)
+    hc, _ = cameras(hs)
+    scene = hs.builder.commit(0)
+    port = 29600 + os.getpid() % 300
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        want, _ = scene.render(hc, 5, hs.max_depth, hs.background)
+        film, stats = render_scene_sharded(scene, hc, 5, hs.max_depth, hs.background)
+        assert shard_range(5, 0, 1) == (0, 5) and stats["paths"] == 5 * hc.width * hc.height
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert np.array_equal(film.cpu().numpy(), want)
+    finally:
+        dist.destroy_process_group()
+        scene.close()
