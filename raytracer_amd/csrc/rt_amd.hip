@@ -341,8 +341,48 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
 #define RT_WIDE_FETCH_THRESHOLD 16
 // PROF: also adds up, per wavefront, the clock cycles spent handing out rays / in node steps / in primitive steps, the
 // number of each and the lanes that took part (development aid: RT_WIDE_PROF=1 prints the sums after a render).
+// What the primitive tests of a lane do not touch -- the reciprocal direction, the grid coefficients, the interval at
+// the top level, the cursor -- stays in LDS while they run: they are the kernel's register peak, and without these 25
+// registers a fourth wavefront fits each SIMD.  A node step brings everything back and stores what it changed.
+struct WideAway {
+    float (*f)[64];       // [6]: ax .. bz
+    double (*d)[64];      // [5]: 1 / d, tmin, tmax
+    uint32_t (*u)[64];    // [9]: pending, rev, slot, level, item_first, item_kind, item_counts
+    uint32_t lane;
+    __device__ __forceinline__ void fetch_ray(WLane& ln) const {
+        ln.cur.inv = mk(d[0][lane], d[1][lane], d[2][lane]);
+        ln.tmin = d[3][lane]; ln.tmax = d[4][lane];
+    }
+    __device__ __forceinline__ void fetch_cursor(WLane& ln) const {
+        ln.pending = (unsigned long long)u[1][lane] << 32 | u[0][lane];
+        ln.rev = u[2][lane]; ln.slot = u[3][lane]; ln.level = u[4][lane];
+        ln.item_first = u[5][lane]; ln.item_kind = u[6][lane];
+        ln.item_counts = (unsigned long long)u[8][lane] << 32 | u[7][lane];
+    }
+    __device__ __forceinline__ void stash_cursor(const WLane& ln) const {
+        u[0][lane] = (uint32_t)ln.pending; u[1][lane] = (uint32_t)(ln.pending >> 32);
+        u[2][lane] = ln.rev; u[3][lane] = ln.slot; u[4][lane] = ln.level;
+        u[5][lane] = ln.item_first; u[6][lane] = ln.item_kind;
+        u[7][lane] = (uint32_t)ln.item_counts; u[8][lane] = (uint32_t)(ln.item_counts >> 32);
+    }
+    __device__ __forceinline__ void fetch_all(WLane& ln) const {
+        fetch_ray(ln);
+        fetch_cursor(ln);
+        ln.ax = f[0][lane]; ln.ay = f[1][lane]; ln.az = f[2][lane]; ln.bx = f[3][lane]; ln.by = f[4][lane]; ln.bz = f[5][lane];
+    }
+    __device__ __forceinline__ void stash_all(const WLane& ln) const {
+        stash_cursor(ln);
+        d[0][lane] = ln.cur.inv.x; d[1][lane] = ln.cur.inv.y; d[2][lane] = ln.cur.inv.z; d[3][lane] = ln.tmin; d[4][lane] = ln.tmax;
+        f[0][lane] = ln.ax; f[1][lane] = ln.ay; f[2][lane] = ln.az; f[3][lane] = ln.bx; f[4][lane] = ln.by; f[5][lane] = ln.bz;
+    }
+};
 template <bool PROF>
-__global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work, unsigned long long* prof) {
+__global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work, unsigned long long* prof) {
+    static_assert(TRAV_BLOCK == 64, "one wavefront per workgroup: a column of the arrays below per lane");
+    __shared__ float away_f[6][64];
+    __shared__ double away_d[5][64];
+    __shared__ uint32_t away_u[9][64];
+    WideAway away; away.f = away_f; away.d = away_d; away.u = away_u; away.lane = threadIdx.x & 63u;
     unsigned long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = PROF ? clock64() : 0ull;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
@@ -389,6 +429,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide
                             const double tmin = a.tmin ? a.tmin[idx] : 0.001, tmax = a.tmax ? a.tmax[idx] : RT_INF;
                             const Ray w = ray_world(mk(a.q.ox[idx], a.q.oy[idx], a.q.oz[idx]), mk(a.q.dx[idx], a.q.dy[idx], a.q.dz[idx]));
                             wide_begin(ln, S, W, w, tmin, tmax, trav_best_setup(a, idx));
+                            away.stash_all(ln);
                         }
                     }
                     const uint32_t want = pool_next + (uint32_t)__popcll(mask);
@@ -407,12 +448,12 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 3) k_traverse_wide(DScene S, DWide
         const bool do_prim = n_prim >= a.thr_step || n_prim > n_node;
         if (do_node) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
-            if (ln.state == RT_W_NODE) wide_node_step(W, ln);
+            if (ln.state == RT_W_NODE) { away.fetch_all(ln); wide_node_step(W, ln); away.stash_cursor(ln); }
             if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[1] += clock64() - t0; pc[4]++; pc[7] += (unsigned long long)n_node; }
         }
         if (do_prim) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
-            if (ln.state == RT_W_PRIM) wide_prim_step<false>(S, W, ln, tally);
+            if (ln.state == RT_W_PRIM) wide_prim_step<false>(S, W, ln, tally, away);
             if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[2] += clock64() - t0; pc[5]++; pc[8] += (unsigned long long)n_prim; }
         }
     }

@@ -520,10 +520,20 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln) {
 }
 // The next primitives of the run in progress for a lane in RT_W_PRIM (lane_prim_tests: two planar primitives or four
 // spheres per step).
-template <bool COUNT>
-RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tally) {
+// `Away` says where the parts of the lane state live that the primitive tests do not touch: the kernel keeps them in
+// LDS while those run (its registers are what decides how many wavefronts fit a SIMD) and brings them back here, where
+// they are needed again.  The default keeps everything in the lane.
+struct WideKeepsAll {
+    RT_HD void fetch_ray(WLane&) const {}      // cur.inv, tmin, tmax
+    RT_HD void fetch_cursor(WLane&) const {}   // pending, rev, slot, level, item_*
+    RT_HD void stash_cursor(const WLane&) const {}
+};
+template <bool COUNT, class Away = WideKeepsAll>
+RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tally, const Away& away = Away()) {
     if (ln.kind & 0x200u) {  // lambda = 0: the item is a whole leaf, whose box narrows the interval first
         ln.kind &= ~0x200u;
+        away.fetch_ray(ln);
+        away.fetch_cursor(ln);
         const double2* rb = W.refbox + 3u * ln.slot;
         const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -531,11 +541,11 @@ RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tal
         asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x));
 #endif
         double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
-        if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); return; }
+        if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); away.stash_cursor(ln); return; }
         ln.s = s; ln.e = e;
     }
     if (ln.k < ln.kend) lane_prim_tests<COUNT>(S, ln, tally);
-    if (ln.k >= ln.kend) wide_ascend(ln, W);
+    if (ln.k >= ln.kend) { away.fetch_cursor(ln); wide_ascend(ln, W); away.stash_cursor(ln); }
 }
 
 }  // namespace rt
