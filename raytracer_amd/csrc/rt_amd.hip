@@ -73,6 +73,8 @@ struct Gates {
     const GateInfo* info;  // what the bits are made of
     uint32_t* lists;       // list b starts at lists + b * stride
     uint32_t stride, n;    // n = 0: no gates
+    uint32_t init_hits;    // the kernel that makes a ray also writes "no hit" for it (0: the first launch of the
+                           // traverse phase visits every ray and starts from nothing by itself)
 };
 // Appends slot `dst` of every `alive` thread to the lists its ray (o, d) belongs in: ballot + prefix count per wave and
 // list, one atomic per workgroup and list.  Called by all threads of a 256-thread workgroup together.
@@ -123,7 +125,7 @@ __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, 
         q.born[idx] = iter;
         q.ctr[idx] = rng.ctr;
         q.sig[idx] = ray_signature(*Gp, o, d);
-        if (gates.n) { hb.t[idx] = RT_INF; hb.ref[idx] = RT_NO_HIT; }
+        if (gates.n && gates.init_hits) { hb.t[idx] = RT_INF; hb.ref[idx] = RT_NO_HIT; }
     }
     gates_append(gates, alive, idx, o, d, counts);
 }
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
         Best b = closest_hit_range<COUNT, true, MEDIA>(S, src, tmin, tmax, L, rng, tally, first, first + (a.end - a.first),
                                                        trav_best_setup(a, idx));
         a.hb.t[idx] = b.t; a.hb.ref[idx] = b.ref; a.hb.chain[idx] = b.chain;
-        a.q.ctr[idx] = rng.ctr;
+        if (MEDIA != RT_MEDIA_NONE) a.q.ctr[idx] = rng.ctr;  // (only a medium draws during the walk)
     }
     if (COUNT) tally_flush(tally, tallies);
 }
@@ -688,7 +690,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
         out.ctr[dst] = ctr;
         out.sig[dst] = sig;
-        if (gates.n) { hb_out.t[dst] = RT_INF; hb_out.ref[dst] = RT_NO_HIT; }
+        if (gates.n && gates.init_hits) { hb_out.t[dst] = RT_INF; hb_out.ref[dst] = RT_NO_HIT; }
     }
     gates_append(gates, alive, dst, no, nd, out_count);
 }
@@ -1823,7 +1825,13 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         if ((rc = ensure_workspace(s, (size_t)rows, (size_t)(bsize * nslots), bounce ? 0 : (size_t)rows, gated ? s->gate.n : 0))) return rc;
         Gates gates;
         std::memset(&gates, 0, sizeof gates);
-        if (gated) { gates.info = s->d_gate; gates.lists = s->wl; gates.stride = (uint32_t)s->ws_paths; gates.n = s->gate.n; }
+        // a first stretch that goes to the lockstep kernel visits every ray: it starts from "no hit" itself, and the
+        // kernels that make the rays need not write that
+        const bool first_fresh = s->stretches[0].kind == RT_STRETCH_LOCKSTEP;
+        if (gated) {
+            gates.info = s->d_gate; gates.lists = s->wl; gates.stride = (uint32_t)s->ws_paths; gates.n = s->gate.n;
+            gates.init_hits = first_fresh ? 0u : 1u;
+        }
         HitBuf hb_in = s->hb, hb_out = gated ? s->hb2 : s->hb;
         auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
         // How many rays each launch leaves behind is counted on the device, and the next launch reads it there.  The
@@ -1956,7 +1964,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 TravArgs ta;
                 std::memset(&ta, 0, sizeof ta);
                 ta.q = qin; ta.hb = hb_in; ta.seed = o->seed; ta.segs = segs;
-                if (gated) { ta.resume = 1u; ta.wl = s->wl; ta.wl_count = segs.in_count; }
+                if (gated) { ta.resume = first_fresh ? 0u : 1u; ta.wl = s->wl; ta.wl_count = segs.in_count; }
                 ta.fast = (o->flags & RT_FLAG_FAST_BVH) ? 1u : 0u;
                 if ((rc = launch_traverse(s, ta, count, nocull, upper_in))) return rc;
                 HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
