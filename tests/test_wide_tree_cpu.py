@@ -163,3 +163,71 @@ def test_nearest_first_order_finds_the_same_hits_with_fewer_tests(pairs, cfg):
     print(cfg, "prim ids differing in fast mode:", differing, "prim tests", fast["counters"]["prim_tests"], "vs", plain["counters"]["prim_tests"])
     assert differing <= (0.01 if cfg == "C5" else 0.0)
     assert fast["counters"]["prim_tests"] <= plain["counters"]["prim_tests"]
+
+
+@pytest.mark.parametrize("count, kinds, seed", [
+    (1, "s", 1), (1, "t", 2), (2, "q", 3), (3, "t", 4), (8, "t", 5), (9, "t", 6), (16, "q", 7), (17, "t", 8), (33, "s", 9),
+    (64, "b", 10), (65, "tq", 11), (130, "b", 12), (257, "sq", 13), (700, "t", 14), (300, "stqb", 15), (1200, "s", 16)])
+def test_wide_trees_of_many_shapes_and_sizes(count, kinds, seed):
+    """BVHs of 1 to 1200 objects of one or several kinds (s sphere, t triangle, q quad, b six-sided box) next to two plain
+    objects: a tree of one node, leaves that fill a level-1 node exactly, by one too many, trees of several levels.
+    Rays from inside, from far outside and along the axes (zero direction components); custom intervals."""
+    from oracle import oracle as orc
+    from raytracer_amd import HostBuilder
+    from raytracer_amd.philox import SceneRng
+
+    def make(b):
+        rng = SceneRng(1000 + seed)
+        m = b.mat_lambertian(b.tex_solid(0.5, 0.5, 0.5))
+        lst = b.list_new()
+        for k in range(count):
+            c = rng.vector(-6.0, 6.0)
+            kind = kinds[k % len(kinds)]
+            if kind == "s":
+                b.list_add(lst, b.sphere(c, rng.range(0.1, 0.9), m))
+            elif kind == "t":
+                b.list_add(lst, b.triangle(c, rng.vector(-1, 1), rng.vector(-1, 1), m))
+            elif kind == "q":
+                b.list_add(lst, b.quad(c, rng.vector(-1, 1), rng.vector(-1, 1), m))
+            else:
+                b.list_add(lst, b.slice(b.box(c, (c[0] + rng.range(0.1, 1.0), c[1] + rng.range(0.1, 1.0), c[2] + rng.range(0.1, 1.0)), m)))
+        world = b.list_new()
+        b.list_add(world, b.sphere((0.0, -1000.0, 0.0), 990.0, m))
+        b.list_add(world, b.bvh(lst))
+        b.list_add(world, b.quad((-8.0, -8.0, 9.0), (16.0, 0.0, 0.0), (0.0, 16.0, 0.0), m))
+        b.set_world(b.slice(world))
+
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    make(hb)
+    make(ob)
+    sim = HostSim(hb)
+    rs = np.random.RandomState(seed)
+    n = 1500
+    o = rs.uniform(-7, 7, (n, 3))
+    d = rs.normal(size=(n, 3))
+    o[500:800] = rs.uniform(-1, 1, (300, 3)) * 800.0          # far outside: the f32 box tests run out of precision
+    d[500:800] = -o[500:800] + rs.uniform(-6, 6, (300, 3))
+    axis = rs.randint(0, 3, 300)
+    d[800:1100] = 0.0
+    d[np.arange(800, 1100), axis] = rs.choice([-1.0, 1.0], 300)  # along an axis: two infinite reciprocals
+    tmin = np.full(n, 0.001)
+    tmax = np.full(n, np.inf)
+    tmin[1100:] = rs.uniform(-3.0, 3.0, n - 1100)
+    tmax[1100:] = tmin[1100:] + rs.uniform(0.0, 12.0, n - 1100)
+    rng3 = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.uint32)
+    want = ob.intersect(o, d, tmin, tmax, rng3)
+    L = _stretch_mode()
+    L.sim_set_walk_mode(3)
+    try:
+        got = sim.intersect(o, d, tmin, tmax, rng3)
+        assert L.sim_wide_stretches() == 1
+        L.sim_set_fast_bvh(1)
+        fast = sim.intersect(o, d, tmin, tmax, rng3)
+    finally:
+        L.sim_set_fast_bvh(0)
+        L.sim_set_walk_mode(0)
+    assert 0.2 < want["hit"].mean() < 0.98
+    assert_hits_equal(got, want, exact=True, what=f"{count} x {kinds}")
+    assert np.array_equal(fast["hit"], want["hit"])
+    same = fast["prim"] == want["prim"]
+    assert same.mean() > 0.995 and np.array_equal(fast["t"][same], want["t"][same])
