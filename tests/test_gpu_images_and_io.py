@@ -231,3 +231,60 @@ def test_render_sharded_over_the_nccl_backend_with_one_rank():
     finally:
         dist.destroy_process_group()
         scene.close()
+
+
+@pytest.mark.parametrize("count, kinds", [(1, "t"), (9, "t"), (130, "b"), (300, "stqb"), (1200, "s"), (5000, "tq")])
+def test_wide_kernel_on_random_trees_of_every_kind(count, kinds):
+    """k_traverse_wide through rt_intersect_batch on BVHs of spheres, triangles, quads and boxes (leaves of one kind and
+    of several, trees of one node and of several levels), with rays from inside, from far away, along the axes and with
+    intervals of the caller's: hit, primitive, t, point and normal exactly the oracle's."""
+    from oracle import oracle as orc
+    from raytracer_amd import HostBuilder
+    from raytracer_amd.philox import SceneRng
+
+    def make(b):
+        rng = SceneRng(77 + count)
+        m = b.mat_lambertian(b.tex_solid(0.5, 0.5, 0.5))
+        lst = b.list_new()
+        for k in range(count):
+            c = rng.vector(-6.0, 6.0)
+            kind = kinds[k % len(kinds)]
+            if kind == "s":
+                b.list_add(lst, b.sphere(c, rng.range(0.1, 0.9), m))
+            elif kind == "t":
+                b.list_add(lst, b.triangle(c, rng.vector(-1, 1), rng.vector(-1, 1), m))
+            elif kind == "q":
+                b.list_add(lst, b.quad(c, rng.vector(-1, 1), rng.vector(-1, 1), m))
+            else:
+                b.list_add(lst, b.slice(b.box(c, (c[0] + rng.range(0.1, 1.0), c[1] + rng.range(0.1, 1.0), c[2] + rng.range(0.1, 1.0)), m)))
+        world = b.list_new()
+        b.list_add(world, b.sphere((0.0, -1000.0, 0.0), 990.0, m))
+        b.list_add(world, b.bvh(lst))
+        b.list_add(world, b.quad((-8.0, -8.0, 9.0), (16.0, 0.0, 0.0), (0.0, 16.0, 0.0), m))
+        b.set_world(b.slice(world))
+
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    make(hb)
+    make(ob)
+    scene = hb.commit(0)
+    try:
+        rs = np.random.RandomState(count)
+        n = 20000
+        o = rs.uniform(-7, 7, (n, 3))
+        d = rs.normal(size=(n, 3))
+        o[5000:8000] = rs.uniform(-1, 1, (3000, 3)) * 800.0
+        d[5000:8000] = -o[5000:8000] + rs.uniform(-6, 6, (3000, 3))
+        axis = rs.randint(0, 3, 3000)
+        d[8000:11000] = 0.0
+        d[np.arange(8000, 11000), axis] = rs.choice([-1.0, 1.0], 3000)
+        tmin = np.full(n, 0.001)
+        tmax = np.full(n, np.inf)
+        tmin[11000:] = rs.uniform(-3.0, 3.0, n - 11000)
+        tmax[11000:] = tmin[11000:] + rs.uniform(0.0, 12.0, n - 11000)
+        rng3 = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.uint32)
+        want = ob.intersect(o, d, tmin, tmax, rng3)
+        got = scene.intersect(o, d, tmin, tmax, rng3)
+        assert 0.2 < want["hit"].mean() < 0.98
+        assert_hits_equal(got, want, exact=True, what=f"{count} x {kinds}", uv_exact=False)  # (the ground is a sphere: acos, atan2)
+    finally:
+        scene.close()
