@@ -288,3 +288,37 @@ def test_wide_kernel_on_random_trees_of_every_kind(count, kinds):
         assert_hits_equal(got, want, exact=True, what=f"{count} x {kinds}", uv_exact=False)  # (the ground is a sphere: acos, atan2)
     finally:
         scene.close()
+
+
+def test_bench_line_keeps_its_contract():
+    """bench.py's measure() on reduced workloads: the fields the driver reads, a primary roofline fraction that is a
+    fraction (fp64 valu, between 0 and 1, never the algorithmic-bytes figure), the HBM roofline from measured traffic
+    likewise, and for a tree with BVH entries the fast mode's report."""
+    import argparse
+    import sys
+    import torch
+    from helpers import ROOT
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(width=120, batch_paths=0, scaling="weak", fast_bvh=False, whole_paths=False, queues=False,
+                              split_bounce=False, no_fast_report=False)
+    for config, spp in (("C2", 16), ("C4", 8)):
+        out = bench.measure(args, config, spp, 2, 1, torch, None, 0, 0, 1, False)
+        assert out["metric"] == "Mrays/s" and out["unit"] == "Mrays/s" and out["n_gpus"] == 1 and out["steps"] == 2
+        assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["dtype"] == "f64" and out["vs_baseline"] is None
+        assert out["value"] > 0 and out["ms_per_step"] > 0 and out["config"]["paths_per_step"] > 0
+        assert "workload" in out["config"] and "model" not in out["config"]
+        roof = out["roofline"]
+        assert roof["bound"] == "fp64 valu" and roof["unit"] == "TFLOP/s" and roof["peak"] == bench.FP64_PEAK_TFLOPS
+        assert roof["frac"] is not None and 0.0 < roof["frac"] <= 1.0
+        assert 0.0 < roof["frac_executed"] <= 1.0 and roof["frac_executed"] <= roof["frac_algorithmic"] * 1.0001
+        assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-12
+        assert "cache_served_bytes_per_ray" in roof and roof["avg_launch_ms"] > 0 and roof["launches"] > 0
+        hbm = out.get("roofline_hbm")
+        if hbm is not None:
+            assert hbm["bound"] == "hbm" and hbm["peak"] == bench.HBM_PEAK_GBS and 0.0 < hbm["frac"] <= 1.0
+            assert roof["traffic"] == hbm["traffic"] > 0
+        if config == "C4":
+            fast = out["fast_bvh"]
+            assert fast["prim_id_mismatch_rate"] <= 1e-3 and fast["rays_compared"] > 0 and fast["speedup"] > 0.5
