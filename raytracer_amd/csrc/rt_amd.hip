@@ -607,7 +607,7 @@ __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
 template <bool PLAIN>
-__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
+__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 3) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
                                                        Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
