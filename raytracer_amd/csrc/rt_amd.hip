@@ -177,6 +177,23 @@ __device__ __forceinline__ uint32_t seg_nth(const Segs& segs, uint32_t v) {
     return v < c0 ? v : segs.stride + (v - c0);
 }
 
+// The same over every class region (the tail kernel, whatever the tree).
+__device__ __forceinline__ uint32_t seg_total_all(const Segs& segs) {
+    if (segs.in_count == nullptr) return segs.n;
+    uint32_t total = segs.fresh;
+    for (uint32_t k = 0; k < segs.nclass; ++k) total += segs.in_count[RT_COUNT_STRIDE * k];
+    return total;
+}
+__device__ __forceinline__ uint32_t seg_nth_all(const Segs& segs, uint32_t v) {
+    if (segs.in_count == nullptr) return v;
+    for (uint32_t k = 0; k < segs.nclass; ++k) {
+        const uint32_t c = segs.in_count[RT_COUNT_STRIDE * k];
+        if (v < c) return k * segs.stride + v;
+        v -= c;
+    }
+    return segs.nclass * segs.stride + v;
+}
+
 // What a traverse launch works on: the queue of rays, where the closest hits go, and -- for caller-supplied batches
 // only -- per-ray intervals (a render uses 0.001..inf, camera.rs:363).
 struct TravArgs {
@@ -800,28 +817,58 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
 // after the other, a wide tree (rt_wide.h) by its own walk and everything else by the plain per-lane walk (with so few
 // rays it is the length of the longest path that counts, not how well the lanes are used -- but the wide tree's
 // boxes are tight where the reference's reach the origin, and a deep path through a large mesh is many times shorter
-// there).  n_stretch = 0: the plain walk over the whole tree.  counters[0] += rays traced, counters[1] = max(iteration
+// there).  n_stretch = 0: the plain walk over the whole tree.  A lane whose path has ended takes the next ray of the
+// queue (a wavefront reserves 64 queue positions per atomic on `work`), so the launch needs no more lanes than the device
+// holds at once and its lanes stay in use while rays are left.  counters[0] += rays traced, counters[1] = max(iteration
 // index after the last bounce of any path).
-#define RT_FINISH_MAX (1u << 17)  // rays in flight (upper bound) from which the tail is taken in one launch
+#define RT_FINISH_MAX (1u << 17)      // rays in flight (upper bound) from which the tail is taken in one launch
+#define RT_FINISH_MAX_BVH (1u << 20)  // the same for trees with BVH entries
 template <bool LOCKSTEP, int MEDIA, bool PLAIN>
 __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
     DScene S, uint64_t seed, Segs segs, Queue q, double* lum_r, double* lum_g, double* lum_b, double bgr, double bgg,
     double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters, const Stretch* stretches,
-    uint32_t n_stretch, const DWide* wides, uint32_t fast) {
-    uint32_t n;
-    const uint32_t idx = seg_slot(segs, n);
+    uint32_t n_stretch, const DWide* wides, uint32_t fast, uint32_t* work) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
-    bool alive = idx < n;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t total = seg_total_all(segs);
+    uint32_t pool_next = 0, pool_end = 0;
+    bool exhausted = false;
+    bool alive = false;
     V3 o = mk(0, 0, 0), d = mk(1, 1, 1), beta = mk(0, 0, 0);
     uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
-    if (alive) {
-        o = mk(q.ox[idx], q.oy[idx], q.oz[idx]); d = mk(q.dx[idx], q.dy[idx], q.dz[idx]);
-        beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
-        pix = q.pix[idx]; smp = q.smp[idx]; slot = q.slot[idx]; born = q.born[idx]; ctr = q.ctr[idx];
-    }
     uint32_t rays = 0, last = 0;
-    for (uint32_t it = iter; __ballot(alive) != 0ull; ++it) {
+    uint32_t it = iter;  // the iteration this lane's path is in: every ray of the queue is in iteration `iter`
+    for (;;) {
+        const unsigned long long idle = __ballot(!alive);
+        if (idle != 0ull && !exhausted) {
+            if (pool_next == pool_end) {
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(work, 64u);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                pool_next = base < total ? base : total;
+                pool_end = base + 64u < total ? base + 64u : total;
+                exhausted = base >= total;
+            }
+            if (!exhausted) {
+                const uint32_t mine = pool_next + (uint32_t)__popcll(idle & lt_mask);
+                if (!alive && mine < pool_end) {
+                    const uint32_t idx = seg_nth_all(segs, mine);
+                    o = mk(q.ox[idx], q.oy[idx], q.oz[idx]); d = mk(q.dx[idx], q.dy[idx], q.dz[idx]);
+                    beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
+                    pix = q.pix[idx]; smp = q.smp[idx]; slot = q.slot[idx]; born = q.born[idx]; ctr = q.ctr[idx];
+                    it = iter;
+                    alive = true;
+                }
+                const uint32_t want = pool_next + (uint32_t)__popcll(idle);
+                pool_next = want < pool_end ? want : pool_end;
+            }
+        }
+        if (__ballot(alive) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
         bool hit = false;
         Rec rec;
         rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
@@ -888,6 +935,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
             }
         }
         if (ended) { lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z; alive = false; }
+        it++;
     }
     unsigned long long r = rays;
     uint32_t lt = last;
@@ -1031,6 +1079,7 @@ struct rt_scene {
     uint32_t persist_waves = 0;  // resident wavefronts of the persistent kernel on the whole device
     uint32_t path_waves = 0;     // the same for the whole-path kernel
     uint32_t wide_waves = 0;     // the same for the wide-tree kernel
+    uint32_t n_cus = 1;          // compute units of the device
     std::vector<void*> allocs;
     DScene d;
     const uint4* nodes_nocull = nullptr;  // the tree with every cull box infinite (RT_FLAG_NO_CULL)
@@ -1458,6 +1507,7 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_wide<false>, TRAV_BLOCK, 0));
         if (per_cu < 1) per_cu = 1;
         s->wide_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        s->n_cus = (uint32_t)prop.multiProcessorCount;
     }
     s->committed = true;
     return RT_OK;
@@ -1903,7 +1953,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 return fail(RT_ERR_STATE, "queue empty with batches left");
             }
             const uint32_t r = iter % RT_RING, rn = (iter + 1u) % RT_RING;
-            if ((bounce || (!lockstep && !count)) && injected == nbatches && upper_in <= RT_FINISH_MAX) {
+            if ((bounce || (!lockstep && !count)) && injected == nbatches && upper_in <= (lockstep ? RT_FINISH_MAX : RT_FINISH_MAX_BVH)) {
                 // the tail: every path that is left is followed to its end in one launch
                 DScene d = s->d;
                 if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
@@ -1916,13 +1966,17 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 // (a deep tree's interval slots for 256 lanes would not fit a workgroup's LDS; the kernel has no
                 // workgroup-wide step, so one wavefront per workgroup serves as well)
                 const uint32_t fblock = levels_lds(s, BOUNCE_BLOCK) > 48u * 1024u ? 64u : (uint32_t)BOUNCE_BLOCK;
-                const uint32_t blocks = (upper_in + fblock - 1) / fblock + nclass + 1u;
+                // no more workgroups than the device holds at once (two of 256 lanes per CU): the lanes take the rays
+                // from the queue as they get free
+                const uint32_t resident = s->n_cus * (fblock == 64u ? 8u : 2u);
+                const uint32_t blocks = std::min((upper_in + fblock - 1) / fblock, resident);
                 HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));
+                HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, sm));  // the counter the rays are handed out with
                 HIP_TRY(hipEventRecord(s->ev[1], sm));
 #define FINISH_ARGS d, o->seed, segs, qin, s->lum_r, s->lum_g, s->lum_b, o->background[0], o->background[1], \
                     o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8), s->dev_stretches, \
                     (uint32_t)((lockstep || nocull) ? 0u : s->stretches.size()), s->dev_wides, \
-                    (uint32_t)(((o->flags & RT_FLAG_FAST_BVH) || s->fast_bvh) ? 1u : 0u)
+                    (uint32_t)(((o->flags & RT_FLAG_FAST_BVH) || s->fast_bvh) ? 1u : 0u), s->d_count + 4
 #define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(fblock), \
                                             levels_lds(s, fblock), sm, FINISH_ARGS)
                 if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
