@@ -1563,7 +1563,7 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
                 a.wl_count = a_.wl_count + RT_COUNT_STRIDE * (4u + (uint32_t)st.wide);
             }
             HIP_TRY(hipMemsetAsync(work, 0, 4, s->stream));  // the work counter of this launch
-            static const uint32_t wdiv = getenv("RT_WIDE_DIV") ? (uint32_t)atoi(getenv("RT_WIDE_DIV")) : 1u;
+            static const uint32_t wdiv = getenv("RT_WIDE_DIV") ? (uint32_t)std::max(1, atoi(getenv("RT_WIDE_DIV"))) : 1u;  // development aid
             const uint32_t grid = std::min(waves, s->wide_waves / wdiv);
             a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
             static const int tf = getenv("RT_WIDE_TF") ? atoi(getenv("RT_WIDE_TF")) : RT_WIDE_FETCH_THRESHOLD;
