@@ -52,6 +52,60 @@ def host_cpu():
     return model, logical, usable
 
 
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; None where the file does not say."""
+    seen, phys, core = set(), None, None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if core is not None:
+            seen.add((phys, core))
+    except OSError:
+        return None
+    return len(seen) or None
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` outside a launcher: starts N ranks (one process per GPU) with torch.distributed.run as a
+    child process and returns its exit code.  Runs before anything in this process has touched the GPU
+    (torch.cuda.device_count() does not initialise it); rank 0 of the child prints the JSON line."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if n > have:
+        print(f"bench.py: --gpus {n} asked for, {have} GPU(s) visible: refusing to measure fewer GPUs than asked for",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
+
+
+def reduce_over_ranks(elapsed, rays, paths, dist, device):
+    """The job's time is the slowest rank's (MAX over ranks), its rays and paths the sum over ranks.  `dist` is
+    torch.distributed with an initialised process group, or None for a single process."""
+    if dist is None:
+        return elapsed, rays, paths
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([rays, paths], dtype=torch.float64, device=device)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(tot[0].item()), float(tot[1].item())
+
+
 def cpu_baseline(config, width, max_seconds=18.0):
     """Times the CPU oracle (C++ restatement of the reference, a thread pool over rows standing in for Rayon) on a
     bounded sample of the same workload: same scene and resolution, fewer samples per pixel.  All CPUs this process may
@@ -189,15 +243,7 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
     stats = [s for s in stats if s]  # (a rank whose share of a strong-scaling job is empty renders nothing)
     rays_local = float(sum(s["rays"] for s in stats))
     paths_local = float(sum(s["paths"] for s in stats))
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([rays_local, paths_local], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tot)
-        total_rays, total_paths = float(tot[0].item()), float(tot[1].item())
-    else:
-        total_rays, total_paths = rays_local, paths_local
+    elapsed, total_rays, total_paths = reduce_over_ranks(elapsed, rays_local, paths_local, dist, f"cuda:{local_rank}")
     if rank != 0:
         scene.close()
         return None
@@ -297,7 +343,7 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to use, one rank each (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C2", help="a BASELINE.json configuration (C1..C5, the metric's workloads) or the "
@@ -317,11 +363,24 @@ def main():
     ap.add_argument("--queues", action="store_true", help="RT_FLAG_QUEUES: the queue-based schedule whatever the scene")
     ap.add_argument("--split-bounce", action="store_true", help="RT_FLAG_SPLIT_BOUNCE: separate traverse and shade launches")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: this process starts the N ranks itself, before it has made any GPU call
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): refusing to print a line "
+                         f"for another GPU count than the one asked for")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible: the HIP path is "
+                         f"the only rendering path and every rank renders on a GPU of its own")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only rendering path")
     torch.cuda.set_device(local_rank)
