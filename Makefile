@@ -4,7 +4,7 @@ CXX ?= g++
 ARCH ?= gfx950
 CSRC := raytracer_amd/csrc
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wl,-Bsymbolic -ffp-contract=off -fno-fast-math \
-            -Wall -Wno-unused-function -Iinclude
+            -Wall -Wno-unused-function -Iinclude $(if $(DEV),-DRT_DEV_KNOBS)
 HOSTFLAGS := -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude
 
 all: $(CSRC)/librt_amd.so $(CSRC)/librt_host.so oracle

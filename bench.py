@@ -137,7 +137,8 @@ def cpu_baseline(config, width, max_seconds=18.0):
         st1, dt1 = timed(1, 0, 1)
         one = st1["rays"] / dt1 / 1e6
     return {"value": rate, "unit": "Mrays/s", "cores": threads, "kind": "port", "mpaths_per_s": prate,
-            "value_1thread": one, "cpu_model": model, "host_logical_cpus": logical, "usable_cpus": usable,
+            "value_1thread": one, "cpu_model": model, "host_logical_cpus": logical, "host_physical_cores": physical_cores(),
+            "usable_cpus": usable,
             "runs_mrays_per_s": [r[0] for r in runs],
             "sample": f"{spec.name} {cam.width}x{cam.height}, {spp} spp of the workload's samples, depth {spec.max_depth}, "
                       f"{rays} rays in {dt:.1f} s on {threads} threads (median of 3); C++ restatement of the reference, not Rayon"}
@@ -191,6 +192,37 @@ def fast_bvh_report(scene, cam, spec, film, spp, parity_rate):
     return {"flag": "RT_FLAG_FAST_BVH (opt-in, not the reference's tie rule)", "prim_id_mismatch_rate": differing / max(total, 1),
             "rays_compared": total, "value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "spp": sub,
             "parity_mode_same_spp": st0["rays"] / dt0 / 1e6, "speedup": (st["rays"] / dt) / (st0["rays"] / dt0)}
+
+
+SECTOR = 64  # bytes the memory system moves for a lone 8-byte store (a radiance component written at a path's own slot)
+
+
+def traffic_model(kernel, stats, rays, paths):
+    """HBM bytes per ray of the dominant kernel's launches, from the layout of what they read and write (the scene itself
+    stays in cache): the queue holds 96 B per ray (origin, direction, throughput: 9 f64; pixel, sample, slot, birth,
+    draw index, signature: 6 u32), a closest hit 16 B (t, reference, chain), a work-list entry 4 B, a finished path's
+    radiance 3 f64 stored at its own slot -- three lone stores, a sector each.  Every ray read was written once (camera
+    rays by k_raygen), so rays - paths rays are written by the bounce / shade launches."""
+    if not rays:
+        return None
+    out_rays = rays - paths
+    if kernel.startswith("k_bounce_lockstep"):
+        total = 96.0 * rays + 96.0 * out_rays + 3 * SECTOR * paths
+        what = "96 B read per ray + 96 B written per ray that goes on + 3 sectors of 64 B per finished path"
+    elif kernel.startswith("k_paths_lockstep"):
+        total = 3.0 * SECTOR * paths
+        what = "3 sectors of 64 B per finished path (path state stays in registers)"
+    elif kernel.startswith("traverse phase"):
+        lists = float(sum(s.get("list_rays", 0) for s in stats))
+        # first stretch (lockstep, every ray): ray 48 B + stream position 12 B + signature 4 B read, closest hit 16 B written;
+        # each eight-wide launch, per ray of its work list: list entry 4 B, ray 48 B and closest hit 16 B read (gathers),
+        # closest hit 16 B written
+        total = (64.0 + 16.0) * rays + (4.0 + 48.0 + 16.0 + 16.0) * lists
+        what = ("80 B per ray in the stretch every ray goes through + 84 B per work-list entry of the eight-wide launches "
+                f"({lists / rays:.2f} entries per ray); gathers counted at their useful bytes, not at sector granularity")
+    else:
+        return None
+    return {"bytes_per_ray": total / rays, "what": what, "rays": rays, "paths": paths}
 
 
 def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_rank, world, with_cpu):
@@ -258,16 +290,18 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
                    "spp_total": spp_job, "paths_per_step": int(total_paths / max(steps, 1)), "seed": 42,
                    "parallelism": f"spp-shard x{world}" if world > 1 else "single GPU"},
     }
-    # Per-ray work of this workload from the device counters (untimed passes at reduced spp): with the cull boxes off
-    # the box and primitive tests are exactly the reference algorithm's ("algorithmic"); with them on, what the timed
-    # steps really execute ("executed").
+    # Per-ray work of this workload from the device counters (untimed passes at reduced spp).  "executed": the same
+    # kernels and launches as the timed steps with their tallies switched on (the eight-wide walk included, its f32 child
+    # box tests priced at half an f64 slab test).  "algorithmic": with the cull boxes off, where the box and primitive
+    # tests are exactly the reference algorithm's (the entry-by-entry walk).
     cspp = max(1, min(spp, 4))
     ref = scene.render_into(cam, cspp, spec.max_depth, spec.background, film.data_ptr(), counters=True, cull=False)
     done = scene.render_into(cam, cspp, spec.max_depth, spec.background, film.data_ptr(), counters=True)
     n_node = ref["node_tests"] / ref["rays"]
     prim_bytes = ref["prim_bytes"] / ref["rays"]
     flops_alg = FLOPS_BOX * n_node + ref["prim_flops"] / ref["rays"] + FLOPS_SHADE
-    flops_exec = FLOPS_BOX * (done["node_tests"] + done["cull_tests"]) / done["rays"] + done["prim_flops"] / done["rays"] + FLOPS_SHADE
+    flops_exec = (FLOPS_BOX * (done["node_tests"] + done["cull_tests"]) + 0.5 * FLOPS_BOX * done["wide_tests"] +
+                  done["prim_flops"]) / done["rays"] + FLOPS_SHADE
     b_ray = S_NODE * n_node + prim_bytes + 2 * S_STATE + 2 * S_HIT
     # the dominant kernel (or, for trees with BVH entries, the launches of the traverse phase of one bounce) and its
     # mean duration, measured with HIP events on the library's stream during the timed steps
@@ -291,38 +325,44 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
         alg = rays_per_launch * (flops_alg - shade) / (avg_ms * 1e-3) / 1e12
         exe = rays_per_launch * (flops_exec - shade) / (avg_ms * 1e-3) / 1e12
         prof = profiled(config)
-        roof = {"bound": "fp64 valu", "kernel": kernel, "achieved": alg, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": alg / FP64_PEAK_TFLOPS, "frac_algorithmic": alg / FP64_PEAK_TFLOPS, "frac_executed": exe / FP64_PEAK_TFLOPS,
-                "achieved_executed": exe, "flops_per_ray_algorithmic": flops_alg, "flops_per_ray_executed": flops_exec,
+        roof = {"bound": "fp64 valu", "kernel": kernel, "achieved": exe, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": exe / FP64_PEAK_TFLOPS, "frac_is": "executed", "frac_executed": exe / FP64_PEAK_TFLOPS,
+                "frac_algorithmic": alg / FP64_PEAK_TFLOPS, "achieved_algorithmic": alg,
+                "flops_per_ray_algorithmic": flops_alg, "flops_per_ray_executed": flops_exec,
                 "avg_launch_ms": avg_ms, "launches": launches, "rays_per_launch": rays_per_launch,
                 "kernel_share_of_step": ms_kernel / (elapsed * 1e3),
                 "shade_ms_per_step": sum(s["ms_shade"] for s in stats) / max(steps, 1),
+                "traverse_ms_per_step": sum(s["ms_traverse"] for s in stats) / max(steps, 1),
                 "traffic": None,
-                "note": "algorithmic = the reference's test counts (18 flops per box test; 35 / 60 / 70 / 30 per sphere / "
-                        "planar / quadric / medium test; 100 per bounce shaded), executed = the tests the timed kernels do "
-                        "after culling; FMA contraction is off, so half of the peak is the ceiling for this arithmetic",
+                "note": "frac = executed flops (what the timed kernels do after culling: 18 flops per f64 box test, 9 per f32 "
+                        "child box of an eight-wide tree; 35 / 60 / 70 / 30 per sphere / planar / quadric / medium test; 100 "
+                        "per bounce shaded) x rays per launch / mean launch time / peak, on every workload; "
+                        "frac_algorithmic prices the reference's own test counts instead and can exceed 1 where most of them "
+                        "are culled; FMA contraction is off, so half of the peak is the ceiling for this arithmetic",
                 "work_per_ray": {"reference_node_tests": n_node, "reference_prim_tests": ref["prim_tests"] / ref["rays"],
                                  "executed_node_tests": done["node_tests"] / done["rays"],
                                  "executed_cull_tests": done["cull_tests"] / done["rays"],
+                                 "executed_wide_child_tests": done["wide_tests"] / done["rays"],
                                  "executed_prim_tests": done["prim_tests"] / done["rays"]},
                 "cache_served_bytes_per_ray": b_ray}
         if prof.get("valu_issue"):
             roof["valu_issue_profiled"] = prof["valu_issue"]
+        # HBM bytes of the same launches from what the library knows of its queues (bytes per ray of this run's own
+        # ray, path and work-list counts), with the profiled figure beside it
+        model = traffic_model(kernel, stats, rays_local, paths_local)
         hbm = None
-        bpr = prof.get("hbm_bytes_per_ray")
-        if bpr and prof.get("kernel", "").split("<")[0].split(" ")[0] == kernel.split(" ")[0]:
-            traffic = bpr * rays_per_launch
+        if model is not None:
+            traffic = model["bytes_per_ray"] * rays_per_launch
             roof["traffic"] = traffic
             gbs = traffic / (avg_ms * 1e-3) / 1e9
             hbm = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                   "traffic": traffic, "bytes_per_ray": bpr,
-                   "source": "rocprofv3 FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of this command, per ray of the profiled run "
-                             "(profiles/traffic.json) x the rays of a launch here"}
-        if roof["frac_algorithmic"] > 1.0:
-            # the reference algorithm's flop count is not this hardware's work when most of its tests are culled (trees
-            # with BVH entries): the fraction of the peak is then the executed one
-            roof["frac"], roof["achieved"] = roof["frac_executed"], exe
-            roof["frac_is"] = "executed (the algorithmic figure exceeds the peak: culled tests are not hardware work)"
+                   "traffic": traffic, "traffic_model": model, "traffic_profiled": None}
+            bpr = prof.get("hbm_bytes_per_ray")
+            if bpr and prof.get("kernel", "").split("<")[0].split(" ")[0] == kernel.split(" ")[0]:
+                hbm["traffic_profiled"] = {"bytes_per_ray": bpr, "bytes_per_launch": bpr * rays_per_launch,
+                                           "taken_at_commit": prof.get("commit"),
+                                           "source": "rocprofv3 FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of this command, per ray "
+                                                     "of the profiled run (profiles/traffic.json)"}
         for r in (roof, hbm):
             if r is not None and not (0.0 <= r["frac"] <= 1.0):  # a fraction above 1 would be a modelling error: not reported
                 r["frac_rejected"] = r["frac"]
@@ -398,6 +438,14 @@ def main():
             r = measure(args, cfg, spp, steps, warm, torch, dist, rank, local_rank, world, with_cpu)
             r["valid_metric_line"] = spp == 0  # (a reduced sample count gives a rate, not the configuration's line)
             also.append(r)
+            key = cfg.lower()
+            out[f"{key}_mrays_per_s"] = r["value"]
+            out[f"{key}_mpaths_per_s"] = r["mpaths_per_s"]
+            out[f"{key}_ms_per_step"] = r["ms_per_step"]
+            out[f"{key}_spp"] = r["config"]["spp_total"]
+            out[f"{key}_roofline_frac"] = (r.get("roofline") or {}).get("frac")
+            out[f"{key}_shade_share_of_step"] = ((r.get("roofline") or {}).get("shade_ms_per_step") or 0.0) / r["ms_per_step"]
+            out[f"{key}_gpu_over_cpu"] = r.get("gpu_over_cpu")
         out["also"] = also
     if rank == 0:
         print(json.dumps(out), flush=True)

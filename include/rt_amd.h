@@ -135,7 +135,10 @@ typedef struct rt_render_opts {
     uint32_t flags;       /* RT_FLAG_* */
     uint64_t seed;        /* key of the counter-based generator */
     double background[3]; /* camera.rs:36 */
-    uint64_t batch_paths; /* paths in flight per wavefront batch; 0 = library default */
+    uint64_t batch_paths; /* paths in flight per wavefront batch; 0 = library default: 32 M (scenes without BVH entries)
+                             or 128 M (with), about 270 bytes of workspace each (8.6 / 35 GB, kept by the scene handle
+                             until rt_scene_destroy), never more than a quarter of the device memory free when the
+                             workspace has to grow */
 } rt_render_opts;
 #define RT_FLAG_COUNTERS 1u /* also count BVH box tests and primitive tests (slower) */
 #define RT_FLAG_NO_CULL 2u  /* ignore the conservative cull boxes: do exactly the tests the reference does */
@@ -161,7 +164,8 @@ typedef struct rt_render_opts {
 typedef struct rt_stats {
     uint64_t paths;      /* camera samples traced */
     uint64_t rays;       /* world.hit calls: one per bounce including the camera ray (camera.rs:363,429) */
-    uint64_t node_tests; /* AABB::hit calls, only with RT_FLAG_COUNTERS */
+    uint64_t node_tests; /* AABB::hit calls, only with RT_FLAG_COUNTERS (with RT_FLAG_NO_CULL as well: exactly the
+                            reference's; without it: those the kernels still make, a leaf's box below an eight-wide tree) */
     uint64_t prim_tests; /* primitive / medium hit calls, only with RT_FLAG_COUNTERS */
     uint64_t cull_tests; /* conservative cull-box tests (not in the reference), only with RT_FLAG_COUNTERS */
     uint64_t prim_bytes; /* bytes of the primitive records those calls read (sphere 40, quad/triangle 136, quadric 88,
@@ -182,6 +186,10 @@ typedef struct rt_stats {
     uint32_t lockstep; /* 1 when the scene has no BVH entries: its kernels are k_bounce_lockstep (+ k_finish) /
                           k_traverse_lockstep / k_paths_lockstep, otherwise k_traverse_persistent */
     uint32_t finish_launches;
+    uint64_t list_rays;  /* rays handed out through work lists to the launches that walk eight-wide trees, summed over
+                            those launches (a ray counts once per tree whose bounds it can reach); 0 where no lists are used */
+    uint64_t wide_tests; /* child boxes of the library's eight-wide trees tested (f32; none in the reference), only with
+                            RT_FLAG_COUNTERS and the cull boxes on */
 } rt_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -238,8 +246,9 @@ int rt_intersect_batch(const rt_scene* s, uint64_t seed, const double* o3, const
                        const double* tmax, const uint32_t* rng3, uint64_t n, uint8_t* hit, uint32_t* prim,
                        double* t, double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out);
 
-/* The same for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Every pointer is DEVICE memory on the scene's
+/* The same for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc).  The
+ * call is synchronous: it launches on the scene's own stream and waits for it, so it cannot itself be captured into a
+ * caller's HIP graph.  No counterpart in the reference.  Every pointer is DEVICE memory on the scene's
  * device, owned by the caller; the call allocates nothing, on the device or through any library: what its kernels
  * need beyond these arrays (the closest hits travelling between launches, a work counter) lives in a static device
  * array of the library, 1 MiB + 256 bytes per GPU, held until the process ends.  Hence the limit: n <= 65536 rays per
@@ -279,6 +288,10 @@ int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, 
                     double* film_rgb, rt_stats* stats);
 /* How many of this process's rt_render_multi calls had their films summed by RCCL (diagnostic). */
 uint64_t rt_multi_rccl_reductions(void);
+/* Destroys the RCCL communicators rt_render_multi keeps between calls (one set per list of devices).  Call it before
+ * the process winds down its HIP runtime -- at library unload that runtime may already be gone, so nothing is destroyed
+ * there; a later rt_render_multi creates its communicators anew.  No counterpart in the reference. */
+void rt_multi_shutdown(void);
 
 /* Per-sample radiance of chosen (pixel, sample) pairs: get_ray + ray_color for each (camera.rs:258-264).
  * radiance3 has 3 f64 per pair; nrays (nullable) the number of world.hit calls of each path. */
@@ -288,6 +301,10 @@ int rt_trace_samples(const rt_scene* s, const rt_camera* cam, const rt_render_op
 /* pixel_color / spp, then proccess_color (camera.rs:265-267, point3/color.rs:49-68): host film in, RGB8 out. */
 int rt_tonemap_rgb8(const rt_scene* s, const double* film_rgb, uint32_t width, uint32_t height, uint32_t spp,
                     uint8_t* rgb8);
+
+/* How many device allocations (hipMalloc) this process's calls into the library have made so far (diagnostic: the
+ * test of rt_intersect_batch_noalloc reads it before and after a call).  No counterpart in the reference. */
+uint64_t rt_debug_device_allocs(void);
 
 /* Device self-check used by the tests: evaluates a/b, sqrt(a), 1/a, log(a) elementwise on the GPU so that the
  * host can compare the first three bit for bit (the intersection code relies on them being correctly rounded). */

@@ -1,5 +1,6 @@
 """ctypes bindings of the two shared libraries: librt_amd.so (HIP kernels + C ABI, include/rt_amd.h) and
 librt_host.so (C++ scene-building layer, include/rt_host.h).  Plumbing only: no arithmetic happens here."""
+import atexit
 import ctypes as C
 import os
 
@@ -55,7 +56,7 @@ class rt_stats(C.Structure):
                 ("ms_total", C.c_double), ("ms_traverse", C.c_double), ("ms_shade", C.c_double),
                 ("ms_paths", C.c_double), ("ms_bounce", C.c_double), ("ms_finish", C.c_double), ("traverse_launches", C.c_uint32),
                 ("path_launches", C.c_uint32), ("bounce_launches", C.c_uint32), ("bounces", C.c_uint32),
-                ("lockstep", C.c_uint32), ("finish_launches", C.c_uint32)]
+                ("lockstep", C.c_uint32), ("finish_launches", C.c_uint32), ("list_rays", C.c_uint64), ("wide_tests", C.c_uint64)]
 
 
 RT_FLAG_COUNTERS = 1
@@ -74,7 +75,7 @@ RT_AMD_SYMBOLS = [
     "rt_scene_set_triangles", "rt_scene_set_quadrics", "rt_scene_set_media", "rt_scene_set_xforms",
     "rt_scene_set_nodes", "rt_scene_set_cull_boxes", "rt_scene_commit", "rt_intersect_batch", "rt_render", "rt_render_device",
     "rt_render_multi", "rt_trace_samples", "rt_tonemap_rgb8", "rt_debug_arith", "rt_intersect_batch_noalloc",
-    "rt_scene_set_fast_bvh", "rt_multi_rccl_reductions",
+    "rt_scene_set_fast_bvh", "rt_multi_rccl_reductions", "rt_debug_device_allocs", "rt_multi_shutdown",
 ]
 
 _amd = None
@@ -123,10 +124,15 @@ def amd():
     L.rt_debug_arith.argtypes = [i32, vp, vp, u64, vp, vp, vp, vp]
     for name in RT_AMD_SYMBOLS:
         f = getattr(L, name)
-        if name not in ("rt_scene_create", "rt_scene_destroy", "rt_last_error", "rt_multi_rccl_reductions"):
+        if name not in ("rt_scene_create", "rt_scene_destroy", "rt_last_error", "rt_multi_rccl_reductions", "rt_debug_device_allocs", "rt_multi_shutdown"):
             f.restype = i32
     L.rt_multi_rccl_reductions.argtypes = []
     L.rt_multi_rccl_reductions.restype = u64
+    L.rt_debug_device_allocs.argtypes = []
+    L.rt_debug_device_allocs.restype = u64
+    L.rt_multi_shutdown.argtypes = []
+    L.rt_multi_shutdown.restype = None
+    atexit.register(L.rt_multi_shutdown)  # (RCCL communicators go before the interpreter lets go of the HIP runtime)
     _amd = L
     return L
 

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <iterator>
 #include <limits>
 #include <map>
@@ -127,7 +128,8 @@ static bool read_ppm(const std::string& path, std::vector<uint8_t>& rgb, uint32_
 }
 // PNG (the reference decodes through the `image` crate, texture.rs:90-93): 8- and 16-bit grey, grey + alpha, RGB,
 // RGBA and palette images, filters 0..4; interlaced files are refused.  Alpha is dropped and 16-bit samples keep their
-// high byte, which is what `image`'s to_rgb8() of such a file yields up to rounding.
+// high byte, where `image`'s to_rgb8() rounds (v * 255 + 32767) / 65535: the two differ by one level for some samples
+// (the reference holds no 16-bit image, so that case is unpinned).
 static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 static bool read_png(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h) {
     std::ifstream f(path, std::ios::binary);
@@ -174,7 +176,11 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& rgb, uint32_
     const size_t bits_per_pixel = (size_t)channels * depth;
     const size_t bpp = std::max<size_t>(1, bits_per_pixel / 8);      // the filters' byte distance
     const size_t stride = ((size_t)W * bits_per_pixel + 7) / 8;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)H);
+    // deflate cannot expand beyond 1032 : 1, so a header that promises more than the IDAT data can hold is refused
+    // before anything of that size is allocated (and nothing above 1 GiB decoded is taken at all)
+    const size_t raw_size = (stride + 1) * (size_t)H;
+    if (raw_size > ((size_t)1 << 30) || raw_size / 1032 > idat.size() + 1) return false;
+    std::vector<uint8_t> raw(raw_size);
     uLongf got = (uLongf)raw.size();
     if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return false;
     std::vector<uint8_t> prev(stride, 0), line(stride);
@@ -222,7 +228,12 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& rgb, uint32_
     return true;
 }
 bool read_image_rgb8(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h) {
-    return read_ppm(path, rgb, w, h) || read_png(path, rgb, w, h);
+    try {
+        return read_ppm(path, rgb, w, h) || read_png(path, rgb, w, h);
+    } catch (const std::bad_alloc&) {  // a file too large for this host is a file that cannot be read
+        rgb.clear();
+        return false;
+    }
 }
 TexturePtr ImageTexture::new_or_fallback(const std::string& path) {
     std::vector<uint8_t> rgb;

@@ -43,6 +43,16 @@ static int fail(int code, const char* fmt, ...) {
                                           __FILE__, __LINE__);                                           \
     } while (0)
 
+// Every device allocation of the library goes through here and is counted (rt_debug_device_allocs: the tests of the
+// entry point that must not allocate read the count before and after a call).
+static std::atomic<uint64_t> g_device_allocs{0};
+static hipError_t rt_hip_malloc(void** p, size_t bytes) {
+    g_device_allocs.fetch_add(1);
+    return hipMalloc(p, bytes);
+}
+template <class T>
+static hipError_t rt_hip_malloc(T** p, size_t bytes) { return rt_hip_malloc(reinterpret_cast<void**>(p), bytes); }
+
 // ------------------------------------------------------------------------------------------------ kernels
 #define TRAV_BLOCK 64    // one wavefront per workgroup: no barriers, LDS interval slots per lane
 #define SHADE_BLOCK 256
@@ -210,6 +220,7 @@ struct TravArgs {
     const uint32_t* wl_count;
     int thr_fetch, thr_step;  // wide kernel: lanes that must be waiting before rays are handed out / a step is taken
     uint32_t fast;            // wide kernel: children nearest first (RT_FLAG_FAST_BVH)
+    unsigned long long* list_total;  // wide kernel, nullable: += the length of the work list this launch went through
 };
 __device__ __forceinline__ Best trav_best_setup(const TravArgs& a, uint32_t idx) {
     Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
@@ -224,9 +235,9 @@ __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, 
     tmax = a.tmax ? a.tmax[idx] : RT_INF;
 }
 __device__ __forceinline__ void tally_flush(const Tally& tally, unsigned long long* tallies) {
-    unsigned long long v[5] = {tally.node_tests, tally.prim_tests, tally.prim_bytes, tally.cull_tests, tally.prim_flops};
+    unsigned long long v[6] = {tally.node_tests, tally.prim_tests, tally.prim_bytes, tally.cull_tests, tally.prim_flops, tally.wide_tests};
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
         if ((threadIdx.x & 63) == 0) atomicAdd(&tallies[k], v[k]);
     }
@@ -239,7 +250,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
     uint32_t n;
     const uint32_t idx = seg_slot(a.segs, n);
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    Tally tally = tally_zero();
     // with sorted queues the wavefront walks the copy of the tree without everything its rays' signatures rule out
     uint32_t first = a.first;
     if (a.segs.in_count != nullptr) first += tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
@@ -272,7 +283,7 @@ template <bool COUNT, int MEDIA>
 __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_traverse_persistent(DScene S, TravArgs a, uint32_t* work,
                                                                          unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    Tally tally = tally_zero();
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t pool_next = 0, pool_end = 0;
@@ -395,8 +406,10 @@ struct WideAway {
         f[0][lane] = ln.ax; f[1][lane] = ln.ay; f[2][lane] = ln.az; f[3][lane] = ln.bx; f[4][lane] = ln.by; f[5][lane] = ln.bz;
     }
 };
-template <bool PROF>
-__global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work, unsigned long long* prof) {
+// COUNT: also tallies the tests done (counting passes; the timed launches are the instantiation without it).
+template <bool PROF, bool COUNT = false>
+__global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work, unsigned long long* prof,
+                                                                            unsigned long long* tallies) {
     static_assert(TRAV_BLOCK == 64, "one wavefront per workgroup: a column of the arrays below per lane");
     __shared__ float away_f[6][64];
     __shared__ double away_d[5][64];
@@ -404,13 +417,14 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide
     WideAway away; away.f = away_f; away.d = away_d; away.u = away_u; away.lane = threadIdx.x & 63u;
     unsigned long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = PROF ? clock64() : 0ull;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    Tally tally = tally_zero();
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
     uint32_t idx = 0xFFFFFFFFu;
     const uint32_t total = a.wl ? *a.wl_count : seg_total(a.segs);
+    if (a.wl && a.list_total && blockIdx.x == 0u && lane == 0u) atomicAdd(a.list_total, (unsigned long long)total);
     WLane ln;
     {
         Best none; none.t = RT_INF; none.ref = RT_NO_HIT; none.chain = 0;
@@ -467,12 +481,12 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide
         const bool do_prim = n_prim >= a.thr_step || n_prim > n_node;
         if (do_node) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
-            if (ln.state == RT_W_NODE) { away.fetch_all(ln); wide_node_step(W, ln); away.stash_cursor(ln); }
+            if (ln.state == RT_W_NODE) { away.fetch_all(ln); wide_node_step(W, ln, COUNT ? &tally : nullptr); away.stash_cursor(ln); }
             if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[1] += clock64() - t0; pc[4]++; pc[7] += (unsigned long long)n_node; }
         }
         if (do_prim) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
-            if (ln.state == RT_W_PRIM) wide_prim_step<false>(S, W, ln, tally, away);
+            if (ln.state == RT_W_PRIM) wide_prim_step<COUNT>(S, W, ln, tally, away);
             if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[2] += clock64() - t0; pc[5]++; pc[8] += (unsigned long long)n_prim; }
         }
     }
@@ -481,6 +495,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, 4) k_traverse_wide(DScene S, DWide
         atomicAdd(&prof[9], clock64() - t_begin);
         atomicAdd(&prof[10], 1ull);
     }
+    if (COUNT) tally_flush(tally, tallies);
 }
 
 // Whole paths for trees WITHOUT BVH entries, where every ray does the same work: get_ray, then ray_color as a
@@ -497,7 +512,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, (MEDIA == RT_MEDIA_NONE && PLAIN &
                                                                    unsigned long long* counters,
                                                                    unsigned long long* tallies) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    Tally tally = tally_zero();
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t pool_next = 0, pool_end = 0;
@@ -725,7 +740,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     uint32_t n;
     const uint32_t idx = seg_slot(segs, n);
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    Tally tally = tally_zero();
     bool alive = false;
     V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
     uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
@@ -829,7 +844,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
     double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters, const Stretch* stretches,
     uint32_t n_stretch, const DWide* wides, uint32_t fast, uint32_t* work) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    Tally tally = tally_zero();
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t total = seg_total_all(segs);
@@ -983,7 +998,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_samples(DScene S, rt_camer
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
-    Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+    Tally tally = tally_zero();
     Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
     V3 o, d;
     camera_ray(cam, pixel[i] % cam.width, pixel[i] / cam.width, rng, o, d);
@@ -1359,7 +1374,7 @@ static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
     *out = nullptr;
     size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);  // never hand a kernel a null table
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, bytes));
+    HIP_TRY(rt_hip_malloc(&p, bytes));
     s->allocs.push_back(p);
     HIP_TRY(hipMemset(p, 0, bytes));
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -1473,13 +1488,13 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& r : s->ring_ev) for (auto& e : r) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void**)&s->h_ring, RT_RING * RT_RING_WORDS * 4, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&s->d_ring, RT_RING * RT_RING_WORDS * 4));
+    HIP_TRY(rt_hip_malloc((void**)&s->d_ring, RT_RING * RT_RING_WORDS * 4));
     s->allocs.push_back(s->d_ring);
     HIP_TRY(hipHostMalloc((void**)&s->h_count, 1024, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&s->d_count, 1024));
+    HIP_TRY(rt_hip_malloc((void**)&s->d_count, 1024));
     HIP_TRY(hipMemset(s->d_count, 0, 1024));
     s->allocs.push_back(s->d_count);
-    HIP_TRY(hipMalloc((void**)&s->d_tallies, 64));
+    HIP_TRY(rt_hip_malloc((void**)&s->d_tallies, 64));
     s->allocs.push_back(s->d_tallies);
     {
         hipDeviceProp_t prop;
@@ -1525,7 +1540,7 @@ static int dev_copy_in(std::vector<void*>& keep, const T* host, size_t n, T** ou
     *out = nullptr;
     if (!host) return RT_OK;
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16)));
+    HIP_TRY(rt_hip_malloc(&p, std::max<size_t>(n * sizeof(T), 16)));
     keep.push_back(p);
     HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
     *out = (T*)p;
@@ -1536,7 +1551,7 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
     *out = nullptr;
     if (!want) return RT_OK;
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16)));
+    HIP_TRY(rt_hip_malloc(&p, std::max<size_t>(n * sizeof(T), 16)));
     keep.push_back(p);
     *out = (T*)p;
     return RT_OK;
@@ -1557,23 +1572,30 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
         TravArgs a = a_;
         a.first = st.first; a.end = st.end; a.resume = (k > 0 || a_.resume) ? 1u : 0u;
         a.wl = nullptr; a.wl_count = nullptr;
-        if (st.kind == RT_STRETCH_WIDE && !count && !nocull) {
+        if (st.kind == RT_STRETCH_WIDE && !nocull) {  // (a counting pass with the cull boxes off does the reference's tests)
             if (a_.wl && (uint32_t)st.wide < s->gate.n) {  // a_.wl / a_.wl_count: the lists' base and the counter set
                 a.wl = a_.wl + (size_t)st.wide * s->ws_paths;
                 a.wl_count = a_.wl_count + RT_COUNT_STRIDE * (4u + (uint32_t)st.wide);
             }
             HIP_TRY(hipMemsetAsync(work, 0, 4, s->stream));  // the work counter of this launch
-            static const uint32_t wdiv = getenv("RT_WIDE_DIV") ? (uint32_t)std::max(1, atoi(getenv("RT_WIDE_DIV"))) : 1u;  // development aid
-            const uint32_t grid = std::min(waves, s->wide_waves / wdiv);
-            a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
+#if defined(RT_DEV_KNOBS)  // development build (make DEV=1): grid divisor, thresholds and the cycle profile from the environment
+            static const uint32_t wdiv = getenv("RT_WIDE_DIV") ? (uint32_t)std::max(1, atoi(getenv("RT_WIDE_DIV"))) : 1u;
             static const int tf = getenv("RT_WIDE_TF") ? atoi(getenv("RT_WIDE_TF")) : RT_WIDE_FETCH_THRESHOLD;
             static const int ts = getenv("RT_WIDE_TS") ? atoi(getenv("RT_WIDE_TS")) : RT_WIDE_STEP_THRESHOLD;
-            a.thr_fetch = tf; a.thr_step = ts;
             static const bool prof = getenv("RT_WIDE_PROF") != nullptr;
+#else
+            const uint32_t wdiv = 1u;
+            const int tf = RT_WIDE_FETCH_THRESHOLD, ts = RT_WIDE_STEP_THRESHOLD;
+            const bool prof = false;
+#endif
+            const uint32_t grid = std::min(waves, s->wide_waves / wdiv);
+            a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
+            a.thr_fetch = tf; a.thr_step = ts;
             DWide dw = s->d_wide[(size_t)st.wide];
             dw.fast = (a_.fast || s->fast_bvh) ? 1u : 0u;
-            if (prof) hipLaunchKernelGGL(k_traverse_wide<true>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3));
-            else hipLaunchKernelGGL(k_traverse_wide<false>, dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, nullptr);
+            if (count) hipLaunchKernelGGL((k_traverse_wide<false, true>), dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, nullptr, s->d_tallies);
+            else if (prof) hipLaunchKernelGGL((k_traverse_wide<true>), dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3), nullptr);
+            else hipLaunchKernelGGL((k_traverse_wide<false>), dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, nullptr, nullptr);
         } else if (st.kind == RT_STRETCH_LOCKSTEP) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
             if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes
@@ -1708,12 +1730,12 @@ static int rt_intersect_batch_noalloc_impl(const rt_scene* s_, uint64_t seed, co
 static int ws_queue(rt_scene* s, Queue& q, size_t n) {
     double** f[9] = {&q.ox, &q.oy, &q.oz, &q.dx, &q.dy, &q.dz, &q.br, &q.bg, &q.bb};
     for (auto pp : f) {
-        HIP_TRY(hipMalloc((void**)pp, n * sizeof(double)));
+        HIP_TRY(rt_hip_malloc((void**)pp, n * sizeof(double)));
         s->ws_allocs.push_back(*pp);
     }
     uint32_t** g[6] = {&q.pix, &q.smp, &q.slot, &q.born, &q.ctr, &q.sig};
     for (auto pp : g) {
-        HIP_TRY(hipMalloc((void**)pp, n * sizeof(uint32_t)));
+        HIP_TRY(rt_hip_malloc((void**)pp, n * sizeof(uint32_t)));
         s->ws_allocs.push_back(*pp);
     }
     return RT_OK;
@@ -1732,19 +1754,19 @@ static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits, 
         if ((rc = ws_queue(s, s->qb, paths))) return rc;
     }
     if (hits) {
-        HIP_TRY(hipMalloc((void**)&s->hb.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
-        HIP_TRY(hipMalloc((void**)&s->hb.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
-        HIP_TRY(hipMalloc((void**)&s->hb.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
     }
     if (lists) {  // work lists are in use: a hit buffer for the second queue too, and the lists (one queue's length each)
-        HIP_TRY(hipMalloc((void**)&s->hb2.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb2.t);
-        HIP_TRY(hipMalloc((void**)&s->hb2.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.ref);
-        HIP_TRY(hipMalloc((void**)&s->hb2.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.chain);
-        HIP_TRY(hipMalloc((void**)&s->wl, lists * paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->wl);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb2.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb2.t);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb2.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.ref);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb2.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.chain);
+        HIP_TRY(rt_hip_malloc((void**)&s->wl, lists * paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->wl);
     }
-    HIP_TRY(hipMalloc((void**)&s->lum_r, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
-    HIP_TRY(hipMalloc((void**)&s->lum_g, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
-    HIP_TRY(hipMalloc((void**)&s->lum_b, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
+    HIP_TRY(rt_hip_malloc((void**)&s->lum_r, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
+    HIP_TRY(rt_hip_malloc((void**)&s->lum_g, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
+    HIP_TRY(rt_hip_malloc((void**)&s->lum_b, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
     s->ws_paths = paths;
     s->ws_lum = lum;
     s->ws_hits = hits;
@@ -1786,6 +1808,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
     hipLaunchKernelGGL(k_fill, dim3((3u * npix + 255u) / 256u), dim3(256), 0, sm, film, (size_t)3 * npix,
                        (o->max_depth == 0 && o->spp_count > 0) ? 0.0 : -0.0);
     if (count) HIP_TRY(hipMemsetAsync(s->d_tallies, 0, 64, sm));
+    HIP_TRY(hipMemsetAsync(s->d_count + 16, 0, 8, sm));  // work-list lengths, added up by the launches that use them
 
     const bool lean_paths = s->plain && s->media_mode == RT_MEDIA_NONE;
     const bool fused = !s->has_bvh && !(o->flags & RT_FLAG_QUEUES) && ((o->flags & RT_FLAG_WHOLE_PATHS) != 0 || lean_paths);
@@ -1847,9 +1870,13 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         // and radiance slots per path), and never more than a quarter of the device memory that is free.
         uint64_t dflt = s->has_bvh ? (128ull << 20) : (32ull << 20);
         if (!o->batch_paths) {
+            // whenever the workspace would have to grow: what is free now plus what this scene's workspace already holds
+            // (it is freed before the larger one is allocated)
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && s->ws_paths == 0)
-                dflt = std::min<uint64_t>(dflt, std::max<uint64_t>(1ull << 20, (uint64_t)free_b / 4 / 270));
+            const uint64_t held = (uint64_t)s->ws_paths * 270u;
+            if (dflt > s->ws_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                dflt = std::max<uint64_t>(std::min<uint64_t>(dflt, std::max<uint64_t>(1ull << 20, ((uint64_t)free_b + held) / 4 / 270)),
+                                          std::min<uint64_t>(dflt, s->ws_paths));
         }
         const uint64_t want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : dflt, npix);
         uint32_t spb = (uint32_t)std::max<uint64_t>(1, (want / 4) / npix);  // samples per batch
@@ -1871,7 +1898,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
         // work lists for the launches that walk wide trees: only where more than one launch makes up a bounce (a
         // lone tree's bounds are the scene's: every ray reaches them)
-        const bool gated = !lockstep && !count && !nocull && s->gate.n > 0 && s->stretches.size() > 1;
+        const bool gated = !lockstep && !nocull && s->gate.n > 0 && s->stretches.size() > 1;
         if ((rc = ensure_workspace(s, (size_t)rows, (size_t)(bsize * nslots), bounce ? 0 : (size_t)rows, gated ? s->gate.n : 0))) return rc;
         Gates gates;
         std::memset(&gates, 0, sizeof gates);
@@ -2018,7 +2045,10 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 TravArgs ta;
                 std::memset(&ta, 0, sizeof ta);
                 ta.q = qin; ta.hb = hb_in; ta.seed = o->seed; ta.segs = segs;
-                if (gated) { ta.resume = first_fresh ? 0u : 1u; ta.wl = s->wl; ta.wl_count = segs.in_count; }
+                if (gated) {
+                    ta.resume = first_fresh ? 0u : 1u; ta.wl = s->wl; ta.wl_count = segs.in_count;
+                    ta.list_total = (unsigned long long*)(s->d_count + 16);
+                }
                 ta.fast = (o->flags & RT_FLAG_FAST_BVH) ? 1u : 0u;
                 if ((rc = launch_traverse(s, ta, count, nocull, upper_in))) return rc;
                 HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
@@ -2064,6 +2094,11 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[3]));
     st.ms_total = ms;
+    if (s->has_bvh) {
+        unsigned long long lr = 0;
+        HIP_TRY(hipMemcpy(&lr, s->d_count + 16, 8, hipMemcpyDeviceToHost));
+        st.list_rays = lr;
+    }
     if (count) {
         unsigned long long h[8];
         HIP_TRY(hipMemcpy(h, s->d_tallies, 64, hipMemcpyDeviceToHost));
@@ -2072,7 +2107,9 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         st.prim_bytes = h[2];
         st.cull_tests = h[3];
         st.prim_flops = h[4];
+        st.wide_tests = h[5];
     }
+#if defined(RT_DEV_KNOBS)
     if (getenv("RT_WIDE_PROF") != nullptr) {
         unsigned long long h[64];
         HIP_TRY(hipMemcpy(h, s->d_count + 64, sizeof h, hipMemcpyDeviceToHost));
@@ -2087,6 +2124,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         }
         HIP_TRY(hipMemset(s->d_count + 64, 0, sizeof h));
     }
+#endif
     if (stats) *stats = st;
     return RT_OK;
 }
@@ -2100,7 +2138,7 @@ static int rt_render_impl(const rt_scene* s_, const rt_camera* cam, const rt_ren
     HIP_TRY(hipSetDevice(s->device));
     size_t bytes = (size_t)3 * cam->width * cam->height * sizeof(double);
     void* d_film = nullptr;
-    HIP_TRY(hipMalloc(&d_film, bytes));
+    HIP_TRY(rt_hip_malloc(&d_film, bytes));
     rc = rt_render_device_impl(s, cam, o, d_film, stats);
     if (rc == RT_OK && hipMemcpy(film_rgb, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(RT_ERR_DEVICE, "film copy back failed");
@@ -2200,7 +2238,7 @@ static int rt_render_multi_impl(const rt_scene* const* scenes, int n, const rt_c
             mine.spp_count = base + ((uint32_t)r < extra ? 1u : 0u);
             mine.spp_begin = o->spp_begin + (uint32_t)r * base + std::min<uint32_t>((uint32_t)r, extra);
             hipError_t e = hipSetDevice(scenes[r]->device);
-            if (e == hipSuccess) e = hipMalloc(&me.film, bytes);
+            if (e == hipSuccess) e = rt_hip_malloc(&me.film, bytes);
             if (e != hipSuccess) { me.rc = RT_ERR_DEVICE; me.err = hipGetErrorString(e); return; }
             me.rc = rt_render_device_impl(scenes[r], cam, &mine, me.film, &me.st);
             if (me.rc != RT_OK) me.err = rt_last_error();  // the error text is per thread
@@ -2234,7 +2272,7 @@ static int rt_render_multi_impl(const rt_scene* const* scenes, int n, const rt_c
     void* tmp = nullptr;
     std::vector<double> staging;
     if (rc == RT_OK && hipSetDevice(dev0) != hipSuccess) rc = fail(RT_ERR_DEVICE, "cannot select device %d", dev0);
-    if (rc == RT_OK && n > 1 && !reduced && hipMalloc(&tmp, bytes) != hipSuccess) rc = fail(RT_ERR_DEVICE, "out of device memory");
+    if (rc == RT_OK && n > 1 && !reduced && rt_hip_malloc(&tmp, bytes) != hipSuccess) rc = fail(RT_ERR_DEVICE, "out of device memory");
     for (int r = 1; r < n && rc == RT_OK && !reduced; ++r) {
         const int dev = scenes[r]->device;
         hipError_t e = dev == dev0 ? hipMemcpy(tmp, sh[(size_t)r].film, bytes, hipMemcpyDeviceToDevice)
@@ -2266,7 +2304,7 @@ static int rt_render_multi_impl(const rt_scene* const* scenes, int n, const rt_c
         for (int r = 0; r < n; ++r) {
             const rt_stats& a = sh[(size_t)r].st;
             t.paths += a.paths; t.rays += a.rays; t.node_tests += a.node_tests; t.prim_tests += a.prim_tests;
-            t.cull_tests += a.cull_tests; t.prim_bytes += a.prim_bytes; t.prim_flops += a.prim_flops;
+            t.cull_tests += a.cull_tests; t.prim_bytes += a.prim_bytes; t.prim_flops += a.prim_flops; t.wide_tests += a.wide_tests; t.list_rays += a.list_rays;
             t.ms_total = std::max(t.ms_total, a.ms_total); t.ms_traverse = std::max(t.ms_traverse, a.ms_traverse);
             t.ms_shade = std::max(t.ms_shade, a.ms_shade); t.ms_paths = std::max(t.ms_paths, a.ms_paths);
             t.ms_bounce = std::max(t.ms_bounce, a.ms_bounce); t.ms_finish = std::max(t.ms_finish, a.ms_finish);
@@ -2446,6 +2484,15 @@ int rt_render_multi(const rt_scene* const* scenes, int n, const rt_camera* cam, 
     return guarded([&]() -> int { return rt_render_multi_impl(scenes, n, cam, o, film_rgb, stats); });
 }
 uint64_t rt_multi_rccl_reductions(void) { return g_rccl_reductions.load(); }
+void rt_multi_shutdown(void) {
+    Rccl& r = rccl();
+    std::lock_guard<std::mutex> hold(r.lock);
+    if (r.ok)
+        for (auto& kv : r.comms)
+            for (ncclComm_t c : kv.second) (void)r.CommDestroy(c);
+    r.comms.clear();
+}
+uint64_t rt_debug_device_allocs(void) { return g_device_allocs.load(); }
 int rt_trace_samples(const rt_scene* s_, const rt_camera* cam, const rt_render_opts* o, uint64_t n, const uint32_t* pixel, const uint32_t* sample, double* radiance3, uint32_t* nrays) {
     return guarded([&]() -> int { return rt_trace_samples_impl(s_, cam, o, n, pixel, sample, radiance3, nrays); });
 }

@@ -336,7 +336,13 @@ struct Best {
 struct Tally {
     uint32_t node_tests, prim_tests, prim_bytes, cull_tests;
     uint32_t prim_flops;  // algorithmic: 35 per sphere test, 60 per quad / triangle, 70 per quadric, 30 per medium
+    uint32_t wide_tests;  // child boxes of the eight-wide tree tested (f32, rt_wide.h); none in the reference
 };
+RT_HD Tally tally_zero() {
+    Tally t;
+    t.node_tests = 0; t.prim_tests = 0; t.prim_bytes = 0; t.cull_tests = 0; t.prim_flops = 0; t.wide_tests = 0;
+    return t;
+}
 
 // True when every active lane of the wavefront holds the same x (returned in `first`).  Records addressed through
 // `first` are then fetched once per wavefront with scalar loads instead of once per lane.

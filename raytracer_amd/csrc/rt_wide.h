@@ -444,7 +444,8 @@ RT_HD void wide_ascend(WLane& ln, const DWide& W) {
 // One node for a lane in RT_W_NODE: the reference's narrowing when the node is a leaf's, then its eight child boxes.
 struct WNodeRec { uint4 q0, q1, q2, q3, q4, q5, tail; };  // the first 112 bytes of a node
 RT_HD uint32_t wide_cursor_node(const DWide& W, const WLane& ln) { return wide_node_index(W.K, ln.level, ln.slot >> (RT_WIDE_LOG * ln.level)); }
-RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec) {
+// `tally` (counting passes only): node_tests counts the reference's box test of a leaf, wide_tests the child boxes.
+RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec, Tally* tally = nullptr) {
     const uint32_t k = ln.level;
     const uint4 q0 = rec.q0, q1 = rec.q1, q2 = rec.q2, q3 = rec.q3, q4 = rec.q4, q5 = rec.q5;
     uint32_t axis = 0u;
@@ -464,9 +465,11 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec) {
         asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x));
 #endif
         double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
+        if (tally) tally->node_tests++;
         if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); return; }
         ln.s = s; ln.e = e;
     }
+    if (tally) tally->wide_tests += RT_WIDE;
     const bool inside = k <= W.lambda;
     const double ds = inside ? ln.s : ln.tmin, de = fmin(inside ? ln.e : ln.tmax, ln.best.t);
     float cs = (float)ds, ce = (float)de;
@@ -512,11 +515,11 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec) {
     wide_goto(ln, W, k, j);
 }
 // The same with the node read by the lane itself.
-RT_HD void wide_node_step(const DWide& W, WLane& ln) {
+RT_HD void wide_node_step(const DWide& W, WLane& ln, Tally* tally = nullptr) {
     const uint4* rp = W.nodes + 8u * wide_cursor_node(W, ln);
     WNodeRec rec;
     rec.q0 = rp[0]; rec.q1 = rp[1]; rec.q2 = rp[2]; rec.q3 = rp[3]; rec.q4 = rp[4]; rec.q5 = rp[5]; rec.tail = rp[6];
-    wide_node_step(W, ln, rec);
+    wide_node_step(W, ln, rec, tally);
 }
 // The next primitives of the run in progress for a lane in RT_W_PRIM (lane_prim_tests: two planar primitives or four
 // spheres per step).
@@ -541,6 +544,7 @@ RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tal
         asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x));
 #endif
         double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
+        if (COUNT) tally.node_tests++;
         if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); away.stash_cursor(ln); return; }
         ln.s = s; ln.e = e;
     }

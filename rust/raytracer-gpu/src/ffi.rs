@@ -149,6 +149,8 @@ pub struct RtStats {
     pub bounces: u32,
     pub lockstep: u32,
     pub finish_launches: u32,
+    pub list_rays: u64,
+    pub wide_tests: u64,
 }
 
 #[link(name = "rt_amd")]
@@ -176,6 +178,8 @@ extern "C" {
     pub fn rt_render_device(s: *const RtScene, cam: *const RtCamera, opts: *const RtRenderOpts, film_rgb_device: *mut c_void, stats: *mut RtStats) -> c_int;
     pub fn rt_render_multi(scenes: *const *const RtScene, n: c_int, cam: *const RtCamera, opts: *const RtRenderOpts, film_rgb: *mut f64, stats: *mut RtStats) -> c_int;
     pub fn rt_multi_rccl_reductions() -> u64;
+    pub fn rt_debug_device_allocs() -> u64;
+    pub fn rt_multi_shutdown();
     pub fn rt_trace_samples(s: *const RtScene, cam: *const RtCamera, opts: *const RtRenderOpts, n: u64, pixel: *const u32, sample: *const u32, radiance3: *mut f64, nrays: *mut u32) -> c_int;
     pub fn rt_tonemap_rgb8(s: *const RtScene, film_rgb: *const f64, width: u32, height: u32, spp: u32, rgb8: *mut u8) -> c_int;
     pub fn rt_debug_arith(device: c_int, a: *const f64, b: *const f64, n: u64, quot: *mut f64, root: *mut f64, recip: *mut f64, logv: *mut f64) -> c_int;

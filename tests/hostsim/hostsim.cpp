@@ -95,7 +95,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
         g_wide_steps = 0;
     }
     for (uint64_t i = 0; i < n; ++i) {
-        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+        Tally tally = tally_zero();
         RngPos rng;
         rng.k0 = (uint32_t)seed; rng.k1 = (uint32_t)(seed >> 32);
         rng.pixel = rng3 ? rng3[3 * i] : (uint32_t)i; rng.sample = rng3 ? rng3[3 * i + 1] : 0u; rng.ctr = rng3 ? rng3[3 * i + 2] : 0u;
@@ -177,7 +177,7 @@ extern "C" int sim_trace_samples(const sim_scene* sc, const rt_camera* cam, uint
     double2 slots[RT_MAX_LEVELS];
     Levels L; L.base = slots; L.stride = 1;
     for (uint64_t i = 0; i < n; ++i) {
-        Tally tally; tally.node_tests = 0; tally.prim_tests = 0; tally.prim_bytes = 0; tally.cull_tests = 0; tally.prim_flops = 0;
+        Tally tally = tally_zero();
         Rng rng = rng_make(seed, pixel[i], sample[i], 0u);
         V3 o, d;
         camera_ray(*cam, pixel[i] % cam->width, pixel[i] / cam->width, rng, o, d);

@@ -1,7 +1,8 @@
 """rt_intersect_batch_noalloc, the entry point for callers that cannot allocate device memory: rays and results in the
 caller's device memory, the kernels' own needs in a static device array of the library.  Its results must be those of
 rt_intersect_batch bit for bit -- on two calls in a row, the second smaller, so that whatever the first call left in
-the shared array is seen not to matter."""
+the shared array is seen not to matter -- and that the call makes no device allocation: the library counts its own
+hipMalloc calls (rt_debug_device_allocs), and the device's free memory and torch's allocator do not move either."""
 import ctypes as C
 
 import numpy as np
@@ -25,13 +26,16 @@ def _call(scene, torch, o, d, tmin, tmax, rng3, seed=42):
            "n": torch.zeros((n, 3), dtype=torch.float64, device=dev), "uv": torch.zeros((n, 2), dtype=torch.float64, device=dev),
            "front": torch.zeros(n, dtype=torch.uint8, device=dev)}
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated(scene.device)
+    # three probes of "allocates nothing": the library's own count of its hipMalloc calls, the device's free memory
+    # (hipMemGetInfo) and torch's allocator
+    before = (_lib.amd().rt_debug_device_allocs(), torch.cuda.mem_get_info(scene.device)[0], torch.cuda.memory_allocated(scene.device))
     rc = _lib.amd().rt_intersect_batch_noalloc(scene.h, seed, od6.data_ptr(), tmin_d.data_ptr(), tmax_d.data_ptr(),
                                                rng.data_ptr(), n, out["hit"].data_ptr(), out["prim"].data_ptr(),
                                                out["t"].data_ptr(), out["p"].data_ptr(), out["n"].data_ptr(),
                                                out["uv"].data_ptr(), out["front"].data_ptr())
     assert rc == 0, _lib.last_error()
-    assert torch.cuda.memory_allocated(scene.device) == before
+    after = (_lib.amd().rt_debug_device_allocs(), torch.cuda.mem_get_info(scene.device)[0], torch.cuda.memory_allocated(scene.device))
+    assert after == before, (before, after)
     res = {k: v.cpu().numpy() for k, v in out.items()}
     res["prim"] = res["prim"].view(np.uint32)
     res["ctr"] = rng[2].cpu().numpy().view(np.uint32)
@@ -47,7 +51,9 @@ def test_noalloc_entry_point_equals_intersect_batch(cfg):
     try:
         for count, bounce in ((20000, 1), (3000, 0)):     # two calls in a row, the second with fewer rays
             o, d, rng3 = path_rays(os_, oc, count, bounce)
+            allocs = _lib.amd().rt_debug_device_allocs()
             want = scene.intersect(o, d, 0.001, np.inf, rng3)
+            assert _lib.amd().rt_debug_device_allocs() > allocs    # (the probe does see the allocating entry point)
             got = _call(scene, torch, o, d, 0.001, np.inf, rng3)
             for k in ("hit", "prim", "front", "ctr", "t", "p", "n", "uv"):
                 assert np.array_equal(got[k], want[k]), f"{cfg} bounce {bounce}: {k} differs"

@@ -15,6 +15,7 @@ usage: tools/make_traffic.py <config>=<summary.json>,<bench.json> [...]   (bench
 the kernel-trace pass of that profile)"""
 import json
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,6 +25,10 @@ TRAVERSE = ("k_traverse_lockstep", "k_traverse_wide", "k_traverse_persistent")
 def main():
     path_out = os.path.join(ROOT, "profiles", "traffic.json")
     out = {}
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
     if os.path.exists(path_out):
         with open(path_out) as fh:
             out = json.load(fh)
@@ -42,7 +47,9 @@ def main():
         for name, k in kernels.items():
             base = name.split("<")[0]
             # instantiations whose first template argument (COUNT) is true only run in the untimed counting passes
-            if base not in wanted or (base != "k_traverse_wide" and "<true" in name) or not k["dispatches"]:
+            # (k_traverse_wide's COUNT is its second argument, the first being the cycle profile)
+            counting = name.replace(" ", "").endswith(",true>") if base == "k_traverse_wide" else "<true" in name
+            if base not in wanted or counting or not k["dispatches"]:
                 continue
             names.append(name)
             ms += k["total_ms"]
@@ -55,7 +62,7 @@ def main():
         rays = roof["rays_per_launch"] * roof["launches"] * (line["steps"] + line["warmup"]) / max(line["steps"], 1)
         entry = {"kernel": roof["kernel"], "profiled_kernels": sorted(names), "profiled_rays": rays, "profiled_kernel_ms": ms,
                  "hbm_bytes_per_ray": (2.0 * agg["FETCH_SIZE"] + agg["WRITE_SIZE"]) * 1024.0 / rays,
-                 "source": os.path.relpath(summary, ROOT)}
+                 "source": os.path.relpath(summary, ROOT), "commit": commit}
         if "SQ_INSTS_VALU" in agg:
             entry["valu_issue"] = {
                 "valu_insts": agg["SQ_INSTS_VALU"], "waves": agg.get("SQ_WAVES"), "cycles_per_inst": 4, "simds": 1024,
