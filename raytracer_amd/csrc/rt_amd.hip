@@ -406,6 +406,7 @@ struct WideAway {
         f[0][lane] = ln.ax; f[1][lane] = ln.ay; f[2][lane] = ln.az; f[3][lane] = ln.bx; f[4][lane] = ln.by; f[5][lane] = ln.bz;
     }
 };
+#define RT_REF_CARRIED 0xFFFFFFFEu  // "the closest hit so far is the one the hit buffer already holds" (no such kind)
 // COUNT: also tallies the tests done (counting passes; the timed launches are the instantiation without it).
 template <bool PROF, bool COUNT = false>
 __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work, unsigned long long* prof,
@@ -461,7 +462,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
                             idx = a.wl ? a.wl[mine] : seg_nth(a.segs, mine);
                             const double tmin = a.tmin ? a.tmin[idx] : 0.001, tmax = a.tmax ? a.tmax[idx] : RT_INF;
                             const Ray w = ray_world(mk(a.q.ox[idx], a.q.oy[idx], a.q.oz[idx]), mk(a.q.dx[idx], a.q.dy[idx], a.q.dz[idx]));
-                            wide_begin(ln, S, W, w, tmin, tmax, trav_best_setup(a, idx));
+                            // going on from an earlier launch's closest hits: only t of that hit is read, and the
+                            // hit is written back only if the tree holds a closer one (the buffer keeps what it has)
+                            Best b0; b0.t = a.resume ? a.hb.t[idx] : RT_INF; b0.ref = a.resume ? RT_REF_CARRIED : RT_NO_HIT; b0.chain = 0u;
+                            wide_begin(ln, S, W, w, tmin, tmax, b0);
                             away.stash_all(ln);
                         }
                     }
@@ -469,7 +473,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
                     pool_next = want < pool_end ? want : pool_end;
                 }
             }
-            if (done_idx != 0xFFFFFFFFu) {
+            if (done_idx != 0xFFFFFFFFu && done_best.ref != RT_REF_CARRIED) {
                 a.hb.t[done_idx] = done_best.t; a.hb.ref[done_idx] = done_best.ref; a.hb.chain[done_idx] = done_best.chain;
             }
             if (exhausted && __ballot(ln.state != RT_W_DONE) == 0ull) break;
@@ -635,11 +639,74 @@ __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8
     if (ctr_out) ctr_out[i] = q.ctr[i];
 }
 
+// Texture::value (texture.rs) for the hits of one workgroup, called by all its threads together.  A perlin texture costs
+// some two thousand f64 instructions (seven octaves of eight gradient lookups, perlin.rs:79-92, then a sine), and a
+// wavefront pays them in full whenever a single one of its rays has hit such a texture -- in final_scene nearly every
+// wavefront, for a lane or two.  So those hits are collected in LDS, evaluated side by side by as few wavefronts as they
+// fill (the same arithmetic on the same point: the same value), and handed back; every other texture is evaluated in place.
+// Returns whether this thread's hit is on a perlin texture, and then its value in `tex`.
+template <int BLOCK>
+__device__ __forceinline__ bool block_perlin_value(const DScene& S, bool wants, uint32_t tex_id, V3 p, V3& tex) {
+    __shared__ double pq[BLOCK][4];       // point, scale; the value comes back in [0]
+    __shared__ uint32_t pslot[BLOCK];     // perlin table
+    __shared__ uint32_t pcount[BLOCK / 64];
+    if (wants) tex_id = tex_resolve(S, tex_id, p);  // past any checker: a solid colour, an image or a perlin texture
+    const bool perl = wants && S.texs[tex_id].kind == RT_TEX_PERLIN;
+    tex = mk(0, 0, 0);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(perl);
+    if (lane == 0u) pcount[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = pcount[w]; base += w < wave ? c : 0u; total += c; }
+    if (total == 0u) return false;  // (the same for every thread of the workgroup)
+    const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (perl) { pq[pos][0] = p.x; pq[pos][1] = p.y; pq[pos][2] = p.z; pq[pos][3] = S.texs[tex_id].scale; pslot[pos] = S.texs[tex_id].a; }
+    __syncthreads();
+    // One wavefront per collected hit, the hits dealt round the workgroup's wavefronts: the 7 x 8 gradient terms of the
+    // turbulence (perlin.rs:46-92) are independent of each other, so lane 8 i + c computes the term of octave i and
+    // corner c; the sums are then taken in the reference's order (corner after corner, octave after octave).
+    for (uint32_t e = wave; e < total; e += BLOCK / 64) {
+        const V3 at = mk(pq[e][0], pq[e][1], pq[e][2]);
+        const double scale = pq[e][3];
+        const double* vec = S.perlin_vec + 768u * pslot[e];
+        const uint32_t* perm = S.perlin_perm + 768u * pslot[e];
+        const uint32_t octave = lane >> 3, corner = lane & 7u;
+        const double two_i = (double)(1u << octave);               // temp_p doubles from octave to octave: exact
+        const V3 tp = mk(at.x * two_i, at.y * two_i, at.z * two_i);
+        const double fx = floor(tp.x), fy = floor(tp.y), fz = floor(tp.z);
+        const double u = tp.x - fx, v = tp.y - fy, w = tp.z - fz;
+        const long long i = (long long)fx, j = (long long)fy, k = (long long)fz;
+        const double uu = u * u * (3.0 - 2.0 * u), vv = v * v * (3.0 - 2.0 * v), ww = w * w * (3.0 - 2.0 * w);
+        const int di = (int)(corner >> 2), dj = (int)((corner >> 1) & 1u), dk = (int)(corner & 1u);
+        const uint32_t fi = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+        const V3 c = ld3(vec + 3u * fi);
+        const double a = (double)di, b = (double)dj, cc = (double)dk;
+        const V3 wv = mk(u - a, v - b, w - cc);
+        const double term = (a * uu + (1.0 - a) * (1.0 - uu)) * (b * vv + (1.0 - b) * (1.0 - vv)) *
+                            (cc * ww + (1.0 - cc) * (1.0 - ww)) * dot(c, wv);
+        double noise = 0.0;  // perlin_noise's accum, its eight terms added in loop order
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) noise += lane_pull((lane & ~7u) + q, term);
+        double accum = 0.0, weight = 1.0;  // perlin_turbulence's
+#pragma unroll
+        for (uint32_t o = 0; o < 7u; ++o) { accum += weight * lane_pull(8u * o, noise); weight *= 0.5; }
+        if (lane == 0u) pq[e][0] = 1.0 + sin(scale * at.z + 10.0 * fabs(accum));  // texture.rs:152-156
+    }
+    __syncthreads();
+    if (perl) tex = mk(0.5, 0.5, 0.5) * pq[pos][0];
+    return perl;
+}
+
 // Material::emitted / scatter on the closest hit, throughput update, termination, and compaction of the
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
 template <bool PLAIN>
-__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 3) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
+__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : RT_SHADE_WAVES) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
                                                        Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
@@ -676,13 +743,19 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 3) k_shade(DScene S, 
             hit = true;
         }
     }
-    // all 64 lanes of every wavefront are back together here, which the shared rejection loop needs
+    // all threads of the workgroup are back together here, which the deferred textures and the shared rejection loop need
+    V3 tex_ready = mk(0, 0, 0);
+    bool tex_is_ready = false;
+    if constexpr (!PLAIN) {
+        if (S.n_perlin != 0u)
+            tex_is_ready = block_perlin_value<SHADE_BLOCK>(S, hit && material_wants_texture(m), m.texture, rec.p, tex_ready);
+    }
     const V3 ruv = wave_unit_vector(hit && scatter_wants_unit_vector<PLAIN>(m), (uint32_t)seed, (uint32_t)(seed >> 32),
                                     pix, smp, ctr);
     if (hit) {
         Rng rng = rng_make(seed, pix, smp, ctr);
         V3 att, emit;
-        if (!scatter_given<PLAIN>(S, m, wd, rec, rng, ruv, nd, att, emit)) {
+        if (!scatter_given<PLAIN, false>(S, m, wd, rec, rng, ruv, nd, att, emit, tex_is_ready, tex_ready)) {
             lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
         } else if (iter - born + 1u == max_depth) {
             // the scattered ray would be traced with depth 0: ray_color returns black (camera.rs:350-352)
@@ -1483,6 +1556,8 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
         else { pv.insert(pv.end(), 768, 0.0); pp.insert(pp.end(), 768, 0u); }
     }
     UP(texels, texels); UP(desc, image_desc); UP(pv, perlin_vec); UP(pp, perlin_perm);
+    d.n_perlin = 0u;
+    for (const rt_texture& t : s->texs) d.n_perlin += t.kind == RT_TEX_PERLIN ? 1u : 0u;
 #undef UP
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));

@@ -192,6 +192,7 @@ __device__ inline V3 wave_unit_vector(bool want, uint32_t k0, uint32_t k1, uint3
     return want ? unit(p) : p;
 }
 #elif defined(__HIPCC__)
+__device__ double lane_pull(uint32_t src_lane, double v);
 __device__ V3 wave_unit_vector(bool want, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t& ctr);
 #endif
 // One draw at position (pixel, sample, ctr) without carrying a cached block around (the tree walk draws at most
@@ -247,6 +248,7 @@ struct DScene {
     const uint32_t* image_desc;   // per slot: first pixel, width, height
     const double* perlin_vec;     // per slot 256*3
     const uint32_t* perlin_perm;  // per slot 3*256
+    uint32_t n_perlin;            // perlin textures in the texture table (0: the shade kernel skips its deferred evaluation)
 };
 
 struct Node {  // rt_node unpacked
@@ -1368,7 +1370,21 @@ RT_HD double perlin_turbulence(const double* vec, const uint32_t* perm, V3 p, in
     }
     return fabs(accum);
 }
+// CheckerTexture::value's choice of child (texture.rs:59-80), followed down to a texture that is not a checker.
+RT_HD uint32_t tex_resolve(const DScene& S, uint32_t tid, V3 p) {
+    for (int guard = 0; guard < 64; ++guard) {
+        if (S.texs[tid].kind != RT_TEX_CHECKER) return tid;
+        const double sc = S.texs[tid].scale;
+        long long xi = (long long)floor(sc * p.x);
+        long long yi = (long long)floor(sc * p.y);
+        long long zi = (long long)floor(sc * p.z);
+        tid = ((xi + yi + zi) % 2 == 0) ? S.texs[tid].a : S.texs[tid].b;
+    }
+    return tid;
+}
 // Texture::value, texture.rs:25-29 (solid), :59-80 (checker), :116-136 (image), :143-157 (perlin).
+// PERLIN = false: the caller has made sure that `tid` is a solid colour or an image (tex_resolve).
+template <bool PERLIN = true>
 RT_HD V3 tex_value(const DScene& S, uint32_t tid, double u, double v, V3 p) {
     for (int guard = 0; guard < 64; ++guard) {
         const rt_texture t = S.texs[tid];
@@ -1393,6 +1409,7 @@ RT_HD V3 tex_value(const DScene& S, uint32_t tid, double u, double v, V3 p) {
             return mk((double)px[0] * sc, (double)px[1] * sc, (double)px[2] * sc);
         }
         // RT_TEX_PERLIN
+        if (!PERLIN) return mk(0, 0, 0);
         const double* vec = S.perlin_vec + 768u * t.a;
         const uint32_t* perm = S.perlin_perm + 768u * t.a;
         return mk(0.5, 0.5, 0.5) * (1.0 + sin(t.scale * p.z + 10.0 * perlin_turbulence(vec, perm, p, 7)));
@@ -1405,7 +1422,10 @@ RT_HD V3 tex_value(const DScene& S, uint32_t tid, double u, double v, V3 p) {
 RT_HD double reflectance(double cosine, double ri) {  // material.rs:161-166
     double r0 = (1.0 - ri) / (1.0 + ri);
     double r0s = r0 * r0;
-    return r0s + (1.0 - r0s) * pow(1.0 - cosine, 5.0);
+    // (1 - cosine)^5 by multiplication: within an ulp or two of the reference's powf(5.0) (material.rs:165), which the
+    // device's pow does not reproduce bit for bit either, at a fraction of its instructions and registers
+    const double x = 1.0 - cosine, x2 = x * x;
+    return r0s + (1.0 - r0s) * (x2 * x2 * x);
 }
 // Whether scatter's first draw is random_unit_vector (Lambertian, Metal, Isotropic; in a plain scene everything
 // but a light).
@@ -1415,9 +1435,15 @@ RT_HD bool scatter_wants_unit_vector(const rt_material& m) {
     return m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_ISOTROPIC;
 }
 // scatter with that vector already drawn (`ruv`, and rng past it); see scatter below.
-template <bool PLAIN = false>
+// `tex_ready`: the material's texture value when the caller has evaluated it already (`tex_is_ready`).
+RT_HD bool material_wants_texture(const rt_material& m) {
+    return m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+}
+// INLINE_PERLIN = false: the caller evaluates perlin textures itself (tex_is_ready for those hits) and this code holds
+// none of their arithmetic.
+template <bool PLAIN = false, bool INLINE_PERLIN = true>
 RT_HD bool scatter_given(const DScene& S, const rt_material& m, V3 ray_d, const Rec& rec, Rng& rng, V3 ruv, V3& out_d,
-                         V3& att, V3& emit) {
+                         V3& att, V3& emit, bool tex_is_ready = false, V3 tex_ready = V3{0.0, 0.0, 0.0}) {
     emit = mk(0, 0, 0);
     if (PLAIN) {
         // the three materials of a plain scene over solid colours: no checker / image / perlin code, no metal, no
@@ -1437,9 +1463,10 @@ RT_HD bool scatter_given(const DScene& S, const rt_material& m, V3 ray_d, const 
     // What several materials share is evaluated once, ahead of the switch, so that a wavefront with a mix of
     // materials runs the texture code once instead of once per material (and the caller the rejection loop: the
     // random unit vector is the first and only thing Lambertian, Metal and Isotropic draw).
-    const bool wants_tex = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+    const bool wants_tex = material_wants_texture(m);
     V3 tex = mk(0, 0, 0);
-    if (wants_tex) tex = tex_value(S, m.texture, rec.u, rec.v, rec.p);
+    if (tex_is_ready) tex = tex_ready;
+    else if (wants_tex) tex = tex_value<INLINE_PERLIN>(S, m.texture, rec.u, rec.v, rec.p);
     switch (m.kind) {
         case RT_MAT_LAMBERTIAN: {  // :45-68
             V3 temp = rec.n + ruv;

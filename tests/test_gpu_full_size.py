@@ -45,7 +45,7 @@ def test_ray_batches_at_the_full_image_size_match_the_oracle(cfg):
                 assert np.array_equal(got[k][solid], want[k][solid]), (cfg, bounce, k)
                 np.testing.assert_allclose(got[k], want[k], rtol=1e-12, atol=1e-9)
             np.testing.assert_allclose(got["uv"], want["uv"], rtol=0, atol=1e-15)
-            assert want["hit"].mean() > 0.5
+            assert want["hit"].mean() > 0.25
     finally:
         scene.close()
 
