@@ -194,24 +194,25 @@ def fast_bvh_report(scene, cam, spec, film, spp, parity_rate):
             "parity_mode_same_spp": st0["rays"] / dt0 / 1e6, "speedup": (st["rays"] / dt) / (st0["rays"] / dt0)}
 
 
-SECTOR = 64  # bytes the memory system moves for a lone 8-byte store (a radiance component written at a path's own slot)
+SECTOR = 64  # bytes the memory system moves for a lone store (a finished path's radiance, written at the path's own slot)
+LUM_SECTORS = 1.25  # the 24 bytes of a radiance start at a multiple of 24: two of every eight slots straddle two sectors
 
 
 def traffic_model(kernel, stats, rays, paths):
     """HBM bytes per ray of the dominant kernel's launches, from the layout of what they read and write (the scene itself
     stays in cache): the queue holds 96 B per ray (origin, direction, throughput: 9 f64; pixel, sample, slot, birth,
     draw index, signature: 6 u32), a closest hit 16 B (t, reference, chain), a work-list entry 4 B, a finished path's
-    radiance 3 f64 stored at its own slot -- three lone stores, a sector each.  Every ray read was written once (camera
+    radiance 3 consecutive f64 stored at its own slot -- a lone store of one sector, sometimes two.  Every ray read was written once (camera
     rays by k_raygen), so rays - paths rays are written by the bounce / shade launches."""
     if not rays:
         return None
     out_rays = rays - paths
     if kernel.startswith("k_bounce_lockstep"):
-        total = 96.0 * rays + 96.0 * out_rays + 3 * SECTOR * paths
-        what = "96 B read per ray + 96 B written per ray that goes on + 3 sectors of 64 B per finished path"
+        total = 96.0 * rays + 96.0 * out_rays + LUM_SECTORS * SECTOR * paths
+        what = "96 B read per ray + 96 B written per ray that goes on + 1.25 sectors of 64 B per finished path"
     elif kernel.startswith("k_paths_lockstep"):
-        total = 3.0 * SECTOR * paths
-        what = "3 sectors of 64 B per finished path (path state stays in registers)"
+        total = LUM_SECTORS * SECTOR * paths
+        what = "1.25 sectors of 64 B per finished path (path state stays in registers)"
     elif kernel.startswith("traverse phase"):
         lists = float(sum(s.get("list_rays", 0) for s in stats))
         # first stretch (lockstep, every ray): ray 48 B + stream position 12 B + signature 4 B read, closest hit 16 B written;

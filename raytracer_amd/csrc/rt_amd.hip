@@ -426,6 +426,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
     uint32_t idx = 0xFFFFFFFFu;
     const uint32_t total = a.wl ? *a.wl_count : seg_total(a.segs);
     if (a.wl && a.list_total && blockIdx.x == 0u && lane == 0u) atomicAdd(a.list_total, (unsigned long long)total);
+    // Rays per hand-out: the host's figure is sized by the rays in the queue; the list this launch works through may be
+    // far shorter, and its rays are then spread over all the wavefronts there are, down to sixteen each.
+    const uint32_t share = (total / gridDim.x + 15u) & ~15u;
+    const uint32_t chunk = share >= a.chunk ? a.chunk : (share < 16u ? 16u : share);
     WLane ln;
     {
         Best none; none.t = RT_INF; none.ref = RT_NO_HIT; none.chain = 0;
@@ -449,10 +453,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
                 if (pool_next == pool_end) {
                     const int leader = __ffsll((long long)mask) - 1;
                     uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(work, a.chunk);
+                    if ((int)lane == leader) base = atomicAdd(work, chunk);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                     pool_next = base < total ? base : total;
-                    pool_end = (base + a.chunk) < total ? (base + a.chunk) : total;
+                    pool_end = (base + chunk) < total ? (base + chunk) : total;
                     if (base >= total) { pool_end = pool_next; exhausted = true; }
                 }
                 if (!exhausted) {
@@ -575,7 +579,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, (MEDIA == RT_MEDIA_NONE && PLAIN &
             ctr = rp.ctr;
             if (b.ref == RT_NO_HIT) {
                 const V3 lum = beta * mk(bgr, bgg, bgb);
-                lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z;
+                lum_r[3u * (size_t)slot] = lum.x; lum_g[3u * (size_t)slot] = lum.y; lum_b[3u * (size_t)slot] = lum.z;
                 alive = false;
             } else {
                 rec = finalize<false, PLAIN>(S, w, b);
@@ -602,7 +606,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, (MEDIA == RT_MEDIA_NONE && PLAIN &
                 depth++;
                 deepest = deepest > depth ? deepest : depth;
             }
-            if (!alive) { lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z; }
+            if (!alive) { lum_r[3u * (size_t)slot] = lum.x; lum_g[3u * (size_t)slot] = lum.y; lum_b[3u * (size_t)slot] = lum.z; }
         }
     }
     unsigned long long r = rays;
@@ -730,7 +734,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : RT_SHADE_WAVES) k_sha
         beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
         uint32_t ref = hb.ref[idx];
         if (ref == RT_NO_HIT) {
-            lum_r[slot] = beta.x * bgr; lum_g[slot] = beta.y * bgg; lum_b[slot] = beta.z * bgb;
+            lum_r[3u * (size_t)slot] = beta.x * bgr; lum_g[3u * (size_t)slot] = beta.y * bgg; lum_b[3u * (size_t)slot] = beta.z * bgb;
         } else {
             pix = q.pix[idx];
             smp = q.smp[idx];
@@ -756,10 +760,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : RT_SHADE_WAVES) k_sha
         Rng rng = rng_make(seed, pix, smp, ctr);
         V3 att, emit;
         if (!scatter_given<PLAIN, false>(S, m, wd, rec, rng, ruv, nd, att, emit, tex_is_ready, tex_ready)) {
-            lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
+            lum_r[3u * (size_t)slot] = beta.x * emit.x; lum_g[3u * (size_t)slot] = beta.y * emit.y; lum_b[3u * (size_t)slot] = beta.z * emit.z;
         } else if (iter - born + 1u == max_depth) {
             // the scattered ray would be traced with depth 0: ray_color returns black (camera.rs:350-352)
-            lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;
+            lum_r[3u * (size_t)slot] = 0.0; lum_g[3u * (size_t)slot] = 0.0; lum_b[3u * (size_t)slot] = 0.0;
         } else {
             beta = beta * att;
             no = rec.p;
@@ -843,7 +847,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
         beta = mk(q.br[at], q.bg[at], q.bb[at]);
         pix = rp.pixel; smp = rp.sample; ctr = rp.ctr;
         if (b.ref == RT_NO_HIT) {
-            lum_r[slot] = beta.x * bgr; lum_g[slot] = beta.y * bgg; lum_b[slot] = beta.z * bgb;
+            lum_r[3u * (size_t)slot] = beta.x * bgr; lum_g[3u * (size_t)slot] = beta.y * bgg; lum_b[3u * (size_t)slot] = beta.z * bgb;
         } else {
             Ray w = ray_world(mk(q.ox[at], q.oy[at], q.oz[at]), mk(q.dx[at], q.dy[at], q.dz[at]));
             rec = finalize<false, PLAIN>(S, w, b);
@@ -858,9 +862,9 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
         Rng rng = rng_make(seed, pix, smp, ctr);
         V3 att, emit;
         if (!scatter_given<PLAIN>(S, m, wd, rec, rng, ruv, nd, att, emit)) {
-            lum_r[slot] = beta.x * emit.x; lum_g[slot] = beta.y * emit.y; lum_b[slot] = beta.z * emit.z;
+            lum_r[3u * (size_t)slot] = beta.x * emit.x; lum_g[3u * (size_t)slot] = beta.y * emit.y; lum_b[3u * (size_t)slot] = beta.z * emit.z;
         } else if (iter - born + 1u == max_depth) {
-            lum_r[slot] = 0.0; lum_g[slot] = 0.0; lum_b[slot] = 0.0;  // camera.rs:350-352
+            lum_r[3u * (size_t)slot] = 0.0; lum_g[3u * (size_t)slot] = 0.0; lum_b[3u * (size_t)slot] = 0.0;  // camera.rs:350-352
         } else {
             beta = beta * att;
             no = rec.p;
@@ -1022,7 +1026,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
                 ctr = rng.ctr;
             }
         }
-        if (ended) { lum_r[slot] = lum.x; lum_g[slot] = lum.y; lum_b[slot] = lum.z; alive = false; }
+        if (ended) { lum_r[3u * (size_t)slot] = lum.x; lum_g[3u * (size_t)slot] = lum.y; lum_b[3u * (size_t)slot] = lum.z; alive = false; }
         it++;
     }
     unsigned long long r = rays;
@@ -1044,7 +1048,7 @@ __global__ void k_film_accumulate(const double* lum_r, const double* lum_g, cons
     double r = film[3u * pix], g = film[3u * pix + 1u], b = film[3u * pix + 2u];
     for (uint32_t s = 0; s < nsamples; ++s) {
         size_t k = (size_t)s * npix + pix;
-        r = r + lum_r[k]; g = g + lum_g[k]; b = b + lum_b[k];
+        r = r + lum_r[3u * k]; g = g + lum_g[3u * k]; b = b + lum_b[3u * k];
     }
     film[3u * pix] = r; film[3u * pix + 1u] = g; film[3u * pix + 2u] = b;
 }
@@ -1839,9 +1843,11 @@ static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits, 
         HIP_TRY(rt_hip_malloc((void**)&s->hb2.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.chain);
         HIP_TRY(rt_hip_malloc((void**)&s->wl, lists * paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->wl);
     }
-    HIP_TRY(rt_hip_malloc((void**)&s->lum_r, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
-    HIP_TRY(rt_hip_malloc((void**)&s->lum_g, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_g);
-    HIP_TRY(rt_hip_malloc((void**)&s->lum_b, lum * sizeof(double))); s->ws_allocs.push_back(s->lum_b);
+    // the radiance of path slot k is three consecutive doubles at 3 k: the three stores of a finished path touch one
+    // 64-byte sector (a second one for a quarter of the slots) instead of three
+    HIP_TRY(rt_hip_malloc((void**)&s->lum_r, 3 * lum * sizeof(double))); s->ws_allocs.push_back(s->lum_r);
+    s->lum_g = s->lum_r + 1;
+    s->lum_b = s->lum_r + 2;
     s->ws_paths = paths;
     s->ws_lum = lum;
     s->ws_hits = hits;
@@ -2031,8 +2037,8 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
             while (accumulated < injected &&
                    (iter - born_at[accumulated] >= o->max_depth || (known_out == 0 && consumed > born_at[accumulated]))) {
                 const uint32_t slot0 = (uint32_t)((accumulated % nslots) * bsize);
-                hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + slot0,
-                                   s->lum_g + slot0, s->lum_b + slot0, npix, batch_samples(accumulated), film);
+                hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + 3 * (size_t)slot0,
+                                   s->lum_g + 3 * (size_t)slot0, s->lum_b + 3 * (size_t)slot0, npix, batch_samples(accumulated), film);
                 accumulated++;
             }
             uint32_t fresh = 0;  // camera rays generated for this iteration
@@ -2055,7 +2061,12 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 return fail(RT_ERR_STATE, "queue empty with batches left");
             }
             const uint32_t r = iter % RT_RING, rn = (iter + 1u) % RT_RING;
-            if ((bounce || (!lockstep && !count)) && injected == nbatches && upper_in <= (lockstep ? RT_FINISH_MAX : RT_FINISH_MAX_BVH)) {
+#if defined(RT_DEV_KNOBS)
+            static const uint32_t finish_bvh = getenv("RT_FINISH_BVH") ? (uint32_t)atoi(getenv("RT_FINISH_BVH")) : RT_FINISH_MAX_BVH;
+#else
+            const uint32_t finish_bvh = RT_FINISH_MAX_BVH;
+#endif
+            if ((bounce || (!lockstep && !count)) && injected == nbatches && upper_in <= (lockstep ? RT_FINISH_MAX : finish_bvh)) {
                 // the tail: every path that is left is followed to its end in one launch
                 DScene d = s->d;
                 if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
@@ -2157,8 +2168,8 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         }
         while (accumulated < injected) {  // (a render of depth 0 generates nothing; everything else was added above)
             const uint32_t slot0 = (uint32_t)((accumulated % nslots) * bsize);
-            hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + slot0,
-                               s->lum_g + slot0, s->lum_b + slot0, npix, batch_samples(accumulated), film);
+            hipLaunchKernelGGL(k_film_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, sm, s->lum_r + 3 * (size_t)slot0,
+                               s->lum_g + 3 * (size_t)slot0, s->lum_b + 3 * (size_t)slot0, npix, batch_samples(accumulated), film);
             accumulated++;
         }
         st.bounces = std::min(last_busy, o->max_depth);
