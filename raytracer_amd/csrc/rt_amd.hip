@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, 
         q.slot[idx] = slot0 + j;
         q.born[idx] = iter;
         q.ctr[idx] = rng.ctr;
-        q.sig[idx] = ray_signature(*Gp, o, d);
+        if (Gp->n != 0u) q.sig[idx] = ray_signature(*Gp, o, d);
         if (gates.n && gates.init_hits) { hb.t[idx] = RT_INF; hb.ref[idx] = RT_NO_HIT; }
     }
     gates_append(gates, alive, idx, o, d, counts);
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
     Tally tally = tally_zero();
     // with sorted queues the wavefront walks the copy of the tree without everything its rays' signatures rule out
     uint32_t first = a.first;
-    if (a.segs.in_count != nullptr) first += tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
+    if (a.segs.in_count != nullptr && S.n_variants > 1u) first += tree_without(S, sig_skip_mask(idx < n ? a.q.sig[idx] : 0u));
     if (idx < n) {
         RngPos rng;
         double tmin, tmax;
@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : RT_SHADE_WAVES) k_sha
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
         out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
         out.ctr[dst] = ctr;
-        out.sig[dst] = sig;
+        if (Gp->n != 0u) out.sig[dst] = sig;
         if (gates.n && gates.init_hits) { hb_out.t[dst] = RT_INF; hb_out.ref[dst] = RT_NO_HIT; }
     }
     gates_append(gates, alive, dst, no, nd, out_count);
@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
     m.kind = RT_MAT_DIFFUSE_LIGHT; m.texture = 0; m.param = 0; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0;
     V3 wd = mk(0, 0, 0);
     // the wavefront walks the copy of the tree without everything its rays' signatures rule out
-    const uint32_t first = tree_without(S, sig_skip_mask(idx < n ? q.sig[idx] : 0u));
+    const uint32_t first = S.n_variants > 1u ? tree_without(S, sig_skip_mask(idx < n ? q.sig[idx] : 0u)) : 0u;
     if (idx < n) {
         RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32);
         rp.pixel = q.pix[idx]; rp.sample = q.smp[idx]; rp.ctr = q.ctr[idx];
@@ -1476,7 +1476,9 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
     // tree entries as the kernels read them (rt_records.h), and a second copy with every cull box switched off
     {
         const double* cb = s->cull_boxes.empty() ? nullptr : s->cull_boxes.data();
-        const std::vector<uint32_t> sig = signature_nodes(s->nodes.data(), s->nodes.size(), RT_MAX_SIG);
+        // (signatures sort the queues of trees without BVH entries; with them the queue has one class, wavefronts
+        // practically never agree on a signature, and the kernels neither compute nor store one)
+        const std::vector<uint32_t> sig = s->has_bvh ? std::vector<uint32_t>() : signature_nodes(s->nodes.data(), s->nodes.size(), RT_MAX_SIG);
         {
             DScene h;  // host pointers, for ray_in_chain
             std::memset(&h, 0, sizeof h);
@@ -1641,7 +1643,6 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 // `n_upper`: no fewer rays than the launch will find (it sizes the grid; the kernels read the true numbers themselves).
 static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool nocull, uint32_t n_upper, uint32_t* work = nullptr) {
     if (!work) work = s->d_count + 4;  // the counter the per-lane kernels hand rays out with
-    const size_t lds = levels_lds(s, TRAV_BLOCK);
     DScene d = s->d;
     if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
     // every stretch of the queue starts a workgroup of its own
@@ -1650,6 +1651,8 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
         const Stretch& st = s->stretches[k];
         TravArgs a = a_;
         a.first = st.first; a.end = st.end; a.resume = (k > 0 || a_.resume) ? 1u : 0u;
+        // interval slots for this stretch alone (a deep BVH elsewhere in the tree does not cost this launch its occupancy)
+        const size_t lds = (size_t)std::min(st.levels, s->levels) * TRAV_BLOCK * sizeof(double2);
         a.wl = nullptr; a.wl_count = nullptr;
         if (st.kind == RT_STRETCH_WIDE && !nocull) {  // (a counting pass with the cull boxes off does the reference's tests)
             if (a_.wl && (uint32_t)st.wide < s->gate.n) {  // a_.wl / a_.wl_count: the lists' base and the counter set

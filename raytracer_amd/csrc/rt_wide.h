@@ -320,7 +320,7 @@ inline bool build_wide(const rt_node* nodes, size_t n_nodes, uint32_t root, cons
 #define RT_STRETCH_LOCKSTEP 0
 #define RT_STRETCH_LANES 1
 #define RT_STRETCH_WIDE 2
-struct Stretch { uint32_t first, end; int kind; int wide; };
+struct Stretch { uint32_t first, end; int kind; int wide; uint32_t levels; };  // levels: interval slots per lane its walk needs
 template <class Qualifies>  // int qualifies(uint32_t entry): index of the entry's wide tree, or -1
 inline std::vector<Stretch> build_stretches(const rt_node* nodes, uint32_t nn, bool has_bvh, Qualifies qualifies) {
     std::vector<Stretch> out;
@@ -333,10 +333,13 @@ inline std::vector<Stretch> build_stretches(const rt_node* nodes, uint32_t nn, b
         int kind = uniform ? RT_STRETCH_LOCKSTEP : RT_STRETCH_LANES, w = -1;
         if (!uniform && n.kind == RT_NODE_BVH) { w = qualifies(i); if (w >= 0) kind = RT_STRETCH_WIDE; }
         if (!out.empty() && out.back().kind == kind && kind != RT_STRETCH_WIDE) out.back().end = next;
-        else out.push_back({i, next, kind, w});
+        else out.push_back({i, next, kind, w, 1u});
         i = next;
     }
-    if (out.empty()) out.push_back({0u, 0u, RT_STRETCH_LOCKSTEP, -1});
+    if (out.empty()) out.push_back({0u, 0u, RT_STRETCH_LOCKSTEP, -1, 1u});
+    for (Stretch& st : out)  // an entry reads the interval of its level; a BVH or MEDIUM entry writes the next one
+        for (uint32_t j = st.first; j < st.end; ++j)
+            st.levels = std::max<uint32_t>(st.levels, nodes[j].level + ((nodes[j].kind == RT_NODE_BVH || nodes[j].kind == RT_NODE_MEDIUM) ? 2u : 1u));
     return out;
 }
 
