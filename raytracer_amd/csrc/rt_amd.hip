@@ -430,6 +430,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
     // far shorter, and its rays are then spread over all the wavefronts there are, down to sixteen each.
     const uint32_t share = (total / gridDim.x + 15u) & ~15u;
     const uint32_t chunk = share >= a.chunk ? a.chunk : (share < 16u ? 16u : share);
+    uint32_t seen = 0u;  // how far the list had been handed out when this wavefront last took from it
     WLane ln;
     {
         Best none; none.t = RT_INF; none.ref = RT_NO_HIT; none.chain = 0;
@@ -451,12 +452,18 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
             if (need) idx = 0xFFFFFFFFu;
             if (!exhausted) {
                 if (pool_next == pool_end) {
+                    // shorter hand-outs as the list runs out (half of an even share of what was left at this wavefront's
+                    // last one), so that the launch does not end on a few wavefronts working through long ones
+                    const uint32_t left = total > seen ? total - seen : 0u;
+                    const uint32_t even = (left / gridDim.x / 2u + 15u) & ~15u;
+                    const uint32_t take = even >= chunk ? chunk : (even < 16u ? 16u : even);
                     const int leader = __ffsll((long long)mask) - 1;
                     uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(work, chunk);
+                    if ((int)lane == leader) base = atomicAdd(work, take);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                    seen = base + take;
                     pool_next = base < total ? base : total;
-                    pool_end = (base + chunk) < total ? (base + chunk) : total;
+                    pool_end = (base + take) < total ? (base + take) : total;
                     if (base >= total) { pool_end = pool_next; exhausted = true; }
                 }
                 if (!exhausted) {
@@ -1184,6 +1191,7 @@ struct rt_scene {
     uint32_t* h_ring = nullptr;           // pinned copy
     // render workspace, grown on demand
     size_t ws_paths = 0, ws_lum = 0, ws_hits = 0;
+    uint64_t ws_bytes = 0;  // device memory the workspace holds
     std::vector<void*> ws_allocs;
     Queue qa, qb;
     HitBuf hb, hb2;   // closest hits of the rays in qa / qb (hb2 only where work lists are in use)
@@ -1831,6 +1839,7 @@ static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits, 
     hits = std::max(hits, s->ws_hits);
     lists = std::max(lists, s->ws_lists);
     s->ws_paths = s->ws_lum = s->ws_hits = s->ws_lists = 0;
+    s->ws_bytes = 0;
     if (paths) {
         if ((rc = ws_queue(s, s->qa, paths))) return rc;
         if ((rc = ws_queue(s, s->qb, paths))) return rc;
@@ -1855,6 +1864,7 @@ static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits, 
     s->ws_lum = lum;
     s->ws_hits = hits;
     s->ws_lists = lists;
+    s->ws_bytes = (uint64_t)paths * 192u + (uint64_t)hits * 16u + (lists ? (uint64_t)hits * 16u + (uint64_t)lists * paths * 4u : 0u) + (uint64_t)lum * 24u;
     return RT_OK;
 }
 
@@ -1949,27 +1959,6 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         st.rays = h[0];
         st.bounces = (uint32_t)h[1] + 1u;
     } else if (o->max_depth > 0 && o->spp_count > 0) {
-        // Paths in flight: 32 M by default; four times that for a tree with BVH entries, whose launches hand rays to
-        // resident wavefronts and end with a tail of few busy lanes (about 270 bytes of queues, hit buffers, work lists
-        // and radiance slots per path), and never more than a quarter of the device memory that is free.
-        uint64_t dflt = s->has_bvh ? (128ull << 20) : (32ull << 20);
-        if (!o->batch_paths) {
-            // whenever the workspace would have to grow: what is free now plus what this scene's workspace already holds
-            // (it is freed before the larger one is allocated)
-            size_t free_b = 0, total_b = 0;
-            const uint64_t held = (uint64_t)s->ws_paths * 270u;
-            if (dflt > s->ws_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                dflt = std::max<uint64_t>(std::min<uint64_t>(dflt, std::max<uint64_t>(1ull << 20, ((uint64_t)free_b + held) / 4 / 270)),
-                                          std::min<uint64_t>(dflt, s->ws_paths));
-        }
-        const uint64_t want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : dflt, npix);
-        uint32_t spb = (uint32_t)std::max<uint64_t>(1, (want / 4) / npix);  // samples per batch
-        spb = std::min(spb, o->spp_count);
-        const uint64_t bsize = (uint64_t)spb * npix;                      // paths per full batch
-        // no queue larger than the paths this call traces
-        const uint64_t qcap = std::max<uint64_t>(std::min<uint64_t>(want, (uint64_t)npix * o->spp_count), bsize);
-        const uint32_t nbatches = (o->spp_count + spb - 1) / spb;
-        const uint32_t nslots = std::min<uint32_t>(o->max_depth + 1u, nbatches);
         // The queue is a row of regions of qcap slots: the rays that go on land in the region of their signature class
         // (trees without BVH entries; one class otherwise), new camera rays in a region of their own behind those.
         // Trees without BVH entries: one bounce is one kernel (walk, shade and compaction together) or, on request
@@ -1977,12 +1966,41 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         const bool lockstep = !s->has_bvh;
         const bool bounce = lockstep && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
         const uint32_t nclass = lockstep ? 1u << s->sig.n : 1u;
-        const uint64_t rows = (uint64_t)nclass * qcap + bsize;
-        if (rows > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
         const bool nocull = (o->flags & RT_FLAG_NO_CULL) != 0;
         // work lists for the launches that walk wide trees: only where more than one launch makes up a bounce (a
         // lone tree's bounds are the scene's: every ray reaches them)
         const bool gated = !lockstep && !nocull && s->gate.n > 0 && s->stretches.size() > 1;
+        // Paths in flight: 128 M by default, 256 M for a tree with BVH entries (whose launches hand rays to resident
+        // wavefronts and end with a tail of few busy lanes: the larger the launch, the less that weighs) -- as long as the
+        // workspace that takes (two queues of 96 bytes a slot, closest hits, work lists, a radiance slot per path of the
+        // batches in flight) stays within two fifths of the device memory that is free.
+        struct Plan { uint32_t spb, nbatches, nslots; uint64_t bsize, qcap, rows, bytes; };
+        auto plan = [&](uint64_t want) {
+            Plan p;
+            p.spb = (uint32_t)std::max<uint64_t>(1, (want / 4) / npix);  // samples per batch
+            p.spb = std::min(p.spb, o->spp_count);
+            p.bsize = (uint64_t)p.spb * npix;                             // paths per full batch
+            // no queue larger than the paths this call traces
+            p.qcap = std::max<uint64_t>(std::min<uint64_t>(want, (uint64_t)npix * o->spp_count), p.bsize);
+            p.nbatches = (o->spp_count + p.spb - 1) / p.spb;
+            p.nslots = std::min<uint32_t>(o->max_depth + 1u, p.nbatches);
+            p.rows = (uint64_t)nclass * p.qcap + p.bsize;
+            p.bytes = p.rows * (192u + (bounce ? 0u : 16u) + (gated ? 16u + 4u * s->gate.n : 0u)) + p.bsize * p.nslots * 24u;
+            return p;
+        };
+        uint64_t want = std::max<uint64_t>(o->batch_paths ? o->batch_paths : (s->has_bvh ? (256ull << 20) : (128ull << 20)), npix);
+        if (!o->batch_paths) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                // (what this scene's workspace holds already is freed before a larger one is allocated)
+                const uint64_t budget = ((uint64_t)free_b + s->ws_bytes) / 5u * 2u;
+                while (want > npix && want > (1ull << 20) && plan(want).bytes > std::max<uint64_t>(budget, s->ws_bytes)) want = want / 4u * 3u;
+            }
+        }
+        const Plan pl = plan(want);
+        const uint32_t spb = pl.spb, nbatches = pl.nbatches, nslots = pl.nslots;
+        const uint64_t bsize = pl.bsize, qcap = pl.qcap, rows = pl.rows;
+        if (rows > 0x7FFFFFFFull || bsize * nslots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "queue too large");
         if ((rc = ensure_workspace(s, (size_t)rows, (size_t)(bsize * nslots), bounce ? 0 : (size_t)rows, gated ? s->gate.n : 0))) return rc;
         Gates gates;
         std::memset(&gates, 0, sizeof gates);
