@@ -109,3 +109,20 @@ def test_time_is_the_slowest_ranks_and_rays_add_up(tmp_path, world):
         assert rays == 10.0 * world * (world + 1) / 2        # SUM over ranks
         assert paths == 3.0 * world * (world + 1) / 2
     assert bench.reduce_over_ranks(1.5, 2.0, 3.0, None, "cpu") == (1.5, 2.0, 3.0)
+
+
+def test_traffic_model_agrees_with_the_profiled_traffic_on_the_headline_workload():
+    """bench.py's roofline_hbm is priced from the run's own ray and path counts (traffic_model); the committed rocprofv3
+    pass of the same command (FETCH_SIZE doubled + WRITE_SIZE, profiles/traffic.json) must agree within 15 % on C2,
+    where every byte is streamed (no gathers).  Both are per ray of the dominant kernel's launches."""
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+        prof = json.load(fh)["C2"]
+    with open(os.path.join(ROOT, "profiles", "r03_C2_bench.json")) as fh:
+        line = json.loads([l for l in fh if '"metric"' in l][-1])
+    counts = line["roofline_hbm"]["traffic_model"]
+    model = bench.traffic_model("k_bounce_lockstep", [], counts["rays"], counts["paths"])
+    assert prof["kernel"] == "k_bounce_lockstep"
+    assert abs(model["bytes_per_ray"] / prof["hbm_bytes_per_ray"] - 1.0) < 0.15, (model["bytes_per_ray"], prof["hbm_bytes_per_ray"])
+    # and the line itself carries both, with the commit the profile was taken at
+    assert line["roofline_hbm"]["traffic_model"]["bytes_per_ray"] == pytest.approx(model["bytes_per_ray"], rel=1e-9)
+    assert bench.traffic_model("k_finish", [], 10.0, 2.0) is None and bench.traffic_model("k_bounce_lockstep", [], 0.0, 0.0) is None
