@@ -227,9 +227,267 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& rgb, uint32_
     h = H;
     return true;
 }
+// JPEG (the reference decodes textures/earthmap.jpg through the `image` crate, texture.rs:90-93, which hands it to
+// zune-jpeg): baseline and extended sequential DCT, Huffman coded, 8 bits per sample, one (grey) or three (YCbCr)
+// components with sampling factors 1 or 2, restart intervals.  Progressive, arithmetic-coded, lossless, 12-bit and
+// four-component files are refused (ImageTexture then falls back as it does for any unreadable file).  The inverse
+// transform is the 13-bit fixed-point one of the IJG's jidctint, chroma is brought to full size with the IJG's
+// triangle filter ("fancy upsampling"), the colour conversion is JFIF's; decoders agree on such an image to within a
+// level or two per sample, not bit for bit, so texel values are "as decoded here" -- feed PNG or PPM where they matter.
+namespace jpeg {
+struct Huff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool set = false; };
+static void huff_build(Huff& h) {
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        h.valptr[l] = k; h.mincode[l] = code;
+        code += h.bits[l]; k += h.bits[l];
+        h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+        code <<= 1;
+    }
+    h.maxcode[17] = 0x7FFFFFFF;
+    h.set = true;
+}
+struct Bits {
+    const uint8_t* p; const uint8_t* end; uint32_t acc = 0; int n = 0; bool marker = false;
+    int bit() {
+        if (n == 0) {
+            uint8_t b = 0;
+            if (!marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    if (p < end && *p == 0x00) ++p;           // a stuffed zero
+                    else { marker = true; --p; b = 0; }       // a marker: the scan's data end here (zeros from now on)
+                }
+            }
+            acc = b; n = 8;
+        }
+        --n;
+        return (int)((acc >> n) & 1u);
+    }
+    int get(int count) { int v = 0; while (count-- > 0) v = (v << 1) | bit(); return v; }
+    void reset() { n = 0; acc = 0; }
+};
+static int decode(Bits& b, const Huff& h) {
+    int code = 0;
+    for (int l = 1; l <= 16; ++l) {
+        code = (code << 1) | b.bit();
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    return -1;
+}
+static int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
+static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+// jidctint.c's accurate integer inverse DCT (CONST_BITS 13, PASS1_BITS 2) on dequantised coefficients.
+static void idct(const int* in, uint8_t* out, size_t stride) {
+    const int C0298 = 2446, C0390 = 3196, C0541 = 4433, C0765 = 6270, C0899 = 7373, C1175 = 9633, C1501 = 12299, C1847 = 15137,
+              C1961 = 16069, C2053 = 16819, C2562 = 20995, C3072 = 25172;
+    long ws[64];
+    for (int c = 0; c < 8; ++c) {
+        const int* p = in + c;
+        long z2 = p[16], z3 = p[48];
+        long z1 = (z2 + z3) * C0541;
+        long tmp2 = z1 + z3 * (-C1847), tmp3 = z1 + z2 * C0765;
+        z2 = p[0]; z3 = p[32];
+        long tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
+        long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = p[56]; tmp1 = p[40]; tmp2 = p[24]; tmp3 = p[8];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3;
+        long z5 = (z3 + z4) * C1175;
+        tmp0 *= C0298; tmp1 *= C2053; tmp2 *= C3072; tmp3 *= C1501;
+        z1 *= -C0899; z2 *= -C2562; z3 *= -C1961; z4 *= -C0390;
+        z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        auto ds = [](long x) { return (x + (1L << 10)) >> 11; };
+        ws[c] = ds(tmp10 + tmp3); ws[56 + c] = ds(tmp10 - tmp3); ws[8 + c] = ds(tmp11 + tmp2); ws[48 + c] = ds(tmp11 - tmp2);
+        ws[16 + c] = ds(tmp12 + tmp1); ws[40 + c] = ds(tmp12 - tmp1); ws[24 + c] = ds(tmp13 + tmp0); ws[32 + c] = ds(tmp13 - tmp0);
+    }
+    for (int r = 0; r < 8; ++r) {
+        const long* p = ws + 8 * r;
+        long z2 = p[2], z3 = p[6];
+        long z1 = (z2 + z3) * C0541;
+        long tmp2 = z1 + z3 * (-C1847), tmp3 = z1 + z2 * C0765;
+        long tmp0 = (p[0] + p[4]) << 13, tmp1 = (p[0] - p[4]) << 13;
+        long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = p[7]; tmp1 = p[5]; tmp2 = p[3]; tmp3 = p[1];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3;
+        long z5 = (z3 + z4) * C1175;
+        tmp0 *= C0298; tmp1 *= C2053; tmp2 *= C3072; tmp3 *= C1501;
+        z1 *= -C0899; z2 *= -C2562; z3 *= -C1961; z4 *= -C0390;
+        z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        auto px = [](long x) { long v = ((x + (1L << 17)) >> 18) + 128; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+        uint8_t* o = out + stride * r;
+        o[0] = px(tmp10 + tmp3); o[7] = px(tmp10 - tmp3); o[1] = px(tmp11 + tmp2); o[6] = px(tmp11 - tmp2);
+        o[2] = px(tmp12 + tmp1); o[5] = px(tmp12 - tmp1); o[3] = px(tmp13 + tmp0); o[4] = px(tmp13 - tmp0);
+    }
+}
+struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; size_t bw = 0, bh = 0; std::vector<uint8_t> px; };
+}  // namespace jpeg
+static bool read_jpeg(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h) {
+    using namespace jpeg;
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (file.size() < 4 || file[0] != 0xFF || file[1] != 0xD8) return false;
+    uint16_t qt[4][64];
+    bool have_q[4] = {false, false, false, false};
+    Huff dc[4], ac[4];
+    std::vector<Comp> comps;
+    uint32_t W = 0, H = 0;
+    int restart = 0, hmax = 1, vmax = 1;
+    bool have_frame = false;
+    size_t at = 2;
+    auto rd16 = [&](size_t i) { return (uint32_t)file[i] << 8 | file[i + 1]; };
+    while (at + 4 <= file.size()) {
+        if (file[at] != 0xFF) return false;
+        const uint8_t m = file[at + 1];
+        if (m == 0xFF) { ++at; continue; }            // fill bytes
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) { at += 2; continue; }
+        if (m == 0xD9) return false;                  // the image ends without a scan
+        const size_t len = rd16(at + 2);
+        if (len < 2 || at + 2 + len > file.size()) return false;
+        const uint8_t* d = &file[at + 4];
+        const size_t n = len - 2;
+        if (m == 0xDB) {                              // quantisation tables
+            for (size_t i = 0; i < n;) {
+                const int pq = d[i] >> 4, tq = d[i] & 15;
+                if (tq > 3 || pq > 1 || i + 1 + 64u * (pq + 1) > n) return false;
+                for (int k = 0; k < 64; ++k) qt[tq][zigzag[k]] = pq ? (uint16_t)(d[i + 1 + 2 * k] << 8 | d[i + 2 + 2 * k]) : d[i + 1 + k];
+                have_q[tq] = true;
+                i += 1 + 64u * (pq + 1);
+            }
+        } else if (m == 0xC4) {                       // Huffman tables
+            for (size_t i = 0; i < n;) {
+                if (i + 17 > n) return false;
+                const int tc = d[i] >> 4, th = d[i] & 15;
+                if (tc > 1 || th > 3) return false;
+                Huff& t = tc ? ac[th] : dc[th];
+                size_t total = 0;
+                for (int l = 1; l <= 16; ++l) { t.bits[l] = d[i + l]; total += d[i + l]; }
+                if (total > 256 || i + 17 + total > n) return false;
+                std::memcpy(t.vals, d + i + 17, total);
+                huff_build(t);
+                i += 17 + total;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {          // baseline / extended sequential frame
+            if (have_frame || n < 6 || d[0] != 8) return false;
+            H = rd16(at + 5); W = rd16(at + 7);
+            const int nc = d[5];
+            if (W == 0 || H == 0 || (nc != 1 && nc != 3) || n < 6u + 3u * nc) return false;
+            comps.resize((size_t)nc);
+            for (int c = 0; c < nc; ++c) {
+                comps[c].id = d[6 + 3 * c]; comps[c].h = d[7 + 3 * c] >> 4; comps[c].v = d[7 + 3 * c] & 15; comps[c].tq = d[8 + 3 * c];
+                if (comps[c].h < 1 || comps[c].h > 2 || comps[c].v < 1 || comps[c].v > 2 || comps[c].tq > 3) return false;
+                hmax = std::max(hmax, comps[c].h); vmax = std::max(vmax, comps[c].v);
+            }
+            if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }
+            have_frame = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return false;                             // progressive, lossless, arithmetic: not read here
+        } else if (m == 0xDD) {
+            if (n < 2) return false;
+            restart = (int)rd16(at + 4);
+        } else if (m == 0xDA) {                       // the scan (one, holding every component)
+            if (!have_frame || n < 1 || d[0] != comps.size() || n < 1u + 2u * comps.size() + 3u) return false;
+            for (size_t c = 0; c < comps.size(); ++c) {
+                if (d[1 + 2 * c] != comps[c].id) return false;
+                comps[c].td = d[2 + 2 * c] >> 4; comps[c].ta = d[2 + 2 * c] & 15;
+                if (comps[c].td > 3 || comps[c].ta > 3 || !dc[comps[c].td].set || !ac[comps[c].ta].set || !have_q[comps[c].tq]) return false;
+            }
+            const size_t mcux = ((size_t)W + 8u * hmax - 1) / (8u * hmax), mcuy = ((size_t)H + 8u * vmax - 1) / (8u * vmax);
+            if (mcux * mcuy > (1u << 22)) return false;
+            for (Comp& c : comps) { c.bw = mcux * c.h * 8; c.bh = mcuy * c.v * 8; c.px.assign(c.bw * c.bh, 0); c.pred = 0; }
+            Bits b; b.p = d + n; b.end = file.data() + file.size();
+            int coef[64], left = restart;
+            for (size_t my = 0; my < mcuy; ++my)
+                for (size_t mx = 0; mx < mcux; ++mx) {
+                    if (restart && left == 0) {       // a restart marker: byte-align, skip it, reset the predictions
+                        b.reset(); b.marker = false;
+                        while (b.p + 1 < b.end && !(b.p[0] == 0xFF && b.p[1] >= 0xD0 && b.p[1] <= 0xD7)) ++b.p;
+                        if (b.p + 1 < b.end) b.p += 2;
+                        for (Comp& c : comps) c.pred = 0;
+                        left = restart;
+                    }
+                    for (Comp& c : comps)
+                        for (int by = 0; by < c.v; ++by)
+                            for (int bx = 0; bx < c.h; ++bx) {
+                                std::memset(coef, 0, sizeof coef);
+                                const int t = decode(b, dc[c.td]);
+                                if (t < 0 || t > 11) return false;
+                                c.pred += extend(b.get(t), t);
+                                coef[0] = c.pred * qt[c.tq][0];
+                                for (int k = 1; k < 64;) {
+                                    const int rs = decode(b, ac[c.ta]);
+                                    if (rs < 0) return false;
+                                    const int r = rs >> 4, sz = rs & 15;
+                                    if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                                    k += r;
+                                    if (k > 63) return false;
+                                    coef[zigzag[k]] = extend(b.get(sz), sz) * qt[c.tq][zigzag[k]];
+                                    ++k;
+                                }
+                                idct(coef, &c.px[(my * c.v + by) * 8 * c.bw + (mx * c.h + bx) * 8], c.bw);
+                            }
+                    if (restart) --left;
+                }
+            // full-size planes: components sampled at half rate go through the triangle filter, 3/4 nearer + 1/4 farther
+            // sample, columns first (h2v1), then rows (rounding as the IJG's jdsample.c)
+            std::vector<std::vector<uint8_t>> full(comps.size());
+            for (size_t ci = 0; ci < comps.size(); ++ci) {
+                Comp& c = comps[ci];
+                const size_t cw = ((size_t)W * c.h + hmax - 1) / hmax, ch = ((size_t)H * c.v + vmax - 1) / vmax;  // samples that count
+                std::vector<uint8_t> wide;
+                size_t ww = cw;
+                if (c.h == hmax) { wide.resize(cw * ch); for (size_t y = 0; y < ch; ++y) std::memcpy(&wide[y * cw], &c.px[y * c.bw], cw); }
+                else {
+                    ww = 2 * cw; wide.resize(ww * ch);
+                    for (size_t y = 0; y < ch; ++y) {
+                        const uint8_t* in = &c.px[y * c.bw];
+                        uint8_t* o = &wide[y * ww];
+                        for (size_t x = 0; x < cw; ++x) {
+                            const int cur = in[x], prev = in[x ? x - 1 : 0], next = in[x + 1 < cw ? x + 1 : x];
+                            o[2 * x] = (uint8_t)(x == 0 ? cur : (3 * cur + prev + 1) >> 2);
+                            o[2 * x + 1] = (uint8_t)(x + 1 == cw ? cur : (3 * cur + next + 2) >> 2);
+                        }
+                    }
+                }
+                if (c.v == vmax) { full[ci].swap(wide); full[ci].resize(ww * ch); }
+                else {
+                    full[ci].resize(ww * 2 * ch);
+                    for (size_t y = 0; y < ch; ++y)
+                        for (int half = 0; half < 2; ++half) {
+                            const uint8_t* near = &wide[y * ww];
+                            const uint8_t* far = &wide[(half == 0 ? (y ? y - 1 : 0) : (y + 1 < ch ? y + 1 : y)) * ww];
+                            uint8_t* o = &full[ci][(2 * y + half) * ww];
+                            for (size_t x = 0; x < ww; ++x) o[x] = (uint8_t)((3 * near[x] + far[x] + (half == 0 ? 1 : 2)) >> 2);
+                        }
+                }
+                c.bw = ww;  // (row length of the full-size plane)
+            }
+            rgb.assign((size_t)3 * W * H, 0);
+            for (size_t y = 0; y < H; ++y)
+                for (size_t x = 0; x < W; ++x) {
+                    uint8_t* o = &rgb[3 * (y * W + x)];
+                    const int Y = full[0][y * comps[0].bw + x];
+                    if (comps.size() == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; continue; }
+                    const int cb = full[1][y * comps[1].bw + x] - 128, cr = full[2][y * comps[2].bw + x] - 128;
+                    auto clamp = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+                    // JFIF: R = Y + 1.402 Cr, G = Y - 0.344136 Cb - 0.714136 Cr, B = Y + 1.772 Cb (16-bit fixed point, rounded)
+                    o[0] = clamp(Y + ((91881 * cr + 32768) >> 16));
+                    o[1] = clamp(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16));
+                    o[2] = clamp(Y + ((116130 * cb + 32768) >> 16));
+                }
+            w = W; h = H;
+            return true;
+        }
+        at += 2 + len;
+    }
+    return false;
+}
 bool read_image_rgb8(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h) {
     try {
-        return read_ppm(path, rgb, w, h) || read_png(path, rgb, w, h);
+        return read_ppm(path, rgb, w, h) || read_png(path, rgb, w, h) || read_jpeg(path, rgb, w, h);
     } catch (const std::bad_alloc&) {  // a file too large for this host is a file that cannot be read
         rgb.clear();
         return false;

@@ -199,6 +199,26 @@ def test_render_agrees_with_reference_image():
     scene.close()
 
 
+def test_render_agrees_with_the_reference_models_image_above_the_models():
+    """cornell_model at the settings of images/cornell_models_medium_quality.png (600 px, 200 spp, depth 50) against the
+    block means of that image's top third (tests/golden/reference_models_blockmeans.npz): box, light and camera are
+    C4's, the meshes below are the author's own (stand-ins here), so the pin is coarse; see models_image_pin."""
+    import os
+    from helpers import ROOT
+    from raytracer_amd import HostBuilder, camera_new, scenes
+    from test_oracle_pins import models_image_pin
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "reference_models_blockmeans.npz"))
+    spec = scenes.build("C4", HostBuilder(), width=600)
+    cam = camera_new(image_width=600, **spec.camera)
+    scene = spec.builder.commit(0)
+    try:
+        film, _ = scene.render(cam, 200, 50, spec.background)
+        worst = models_image_pin(scene.tonemap(film, 200).astype(np.float64), ref)
+        print("largest block difference against the reference's image:", worst)
+    finally:
+        scene.close()
+
+
 def test_image_rmse_gpu_vs_oracle_at_equal_spp(gpu_scenes):
     """Image check at equal spp and equal random streams.  The two renders trace the same paths except where a
     last-bit difference between libm and the device library (log in the medium, sin in the perlin texture, pow in

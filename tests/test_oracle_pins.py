@@ -286,3 +286,32 @@ def test_oracle_render_agrees_with_reference_image_statistics():
     assert diff.mean() < 2.0, diff.mean()
     assert np.abs(rgb.mean(axis=(0, 1)) - ref["mean"]).max() < 1.5
     assert abs((rgb == 255).mean() - float(ref["frac255"])) < 0.01
+
+
+# ---- the reference's render of cornell_model, with its author's own meshes --------------------------------------------
+def models_image_pin(rgb, ref):
+    """Coarse pin of C4's empty-box radiance: images/cornell_models_medium_quality.png (600 px, 200 spp) shows C4's box,
+    light and camera with the author's pawn and teapot, which the reference's repository does not hold; this build
+    renders stand-ins of other shapes, so only the top third of the image (ceiling, light, upper walls: 2 x 6 blocks of
+    100 x 100 pixels) is compared, and loosely: the models change how much light the box keeps (measured: the
+    reference is 3 to 9 grey levels brighter there).  Returns the largest block difference."""
+    h, w, _ = rgb.shape
+    blocks = rgb.reshape(6, h // 6, 6, w // 6, 3).mean(axis=(1, 3))
+    diff = np.abs(blocks[:2] - ref["blocks"][:2])
+    assert diff.max() < 14.0, diff.max()
+    signed = (ref["blocks"][:2] - blocks[:2]).mean()
+    assert 0.0 < signed < 10.0, signed
+    # the colours the side walls throw on the ceiling: green on the image's left, red on its right
+    left, right = blocks[0, 0], blocks[0, 5]
+    assert left[1] > left[0] and right[0] > 1.5 * right[1]
+    for got, want in ((left, ref["blocks"][0, 0]), (right, ref["blocks"][0, 5])):
+        np.testing.assert_allclose(got / got.sum(), want / want.sum(), atol=0.02)
+    return diff.max()
+
+
+def test_oracle_render_agrees_with_the_reference_models_image_above_the_models():
+    ref = np.load(os.path.join(GOLD, "reference_models_blockmeans.npz"))
+    spec = scenes.build("C4", orc.OracleBuilder(), width=150)
+    cam = orc.camera_new(image_width=150, **spec.camera)
+    film, _ = spec.builder.render(cam, 64, 50, spec.background)
+    models_image_pin(orc.tonemap(film, 64).astype(np.float64), ref)
