@@ -408,7 +408,8 @@ struct WideAway {
 };
 #define RT_REF_CARRIED 0xFFFFFFFEu  // "the closest hit so far is the one the hit buffer already holds" (no such kind)
 // COUNT: also tallies the tests done (counting passes; the timed launches are the instantiation without it).
-template <bool PROF, bool COUNT = false>
+// ONLY: the one kind of primitive the tree's items hold (its tests alone are compiled in), or 0 for any mix.
+template <bool PROF, bool COUNT = false, int ONLY = 0>
 __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DScene S, DWide W, TravArgs a, uint32_t* work, unsigned long long* prof,
                                                                             unsigned long long* tallies) {
     static_assert(TRAV_BLOCK == 64, "one wavefront per workgroup: a column of the arrays below per lane");
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
         }
         if (do_prim) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
-            if (ln.state == RT_W_PRIM) wide_prim_step<COUNT>(S, W, ln, tally, away);
+            if (ln.state == RT_W_PRIM) wide_prim_step<COUNT, WideAway, ONLY>(S, W, ln, tally, away);
             if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[2] += clock64() - t0; pc[5]++; pc[8] += (unsigned long long)n_prim; }
         }
     }
@@ -1608,7 +1609,8 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
         }
         if (per_cu < 1) per_cu = 1;
         s->path_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_wide<false>, TRAV_BLOCK, 0));
+        // (every instantiation of the wide walk holds four wavefronts per SIMD: the launch bound its registers are kept to)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_traverse_wide<false, false, 0>, TRAV_BLOCK, 0));
         if (per_cu < 1) per_cu = 1;
         s->wide_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
         s->n_cus = (uint32_t)prop.multiProcessorCount;
@@ -1685,7 +1687,15 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
             dw.fast = (a_.fast || s->fast_bvh) ? 1u : 0u;
             if (count) hipLaunchKernelGGL((k_traverse_wide<false, true>), dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, nullptr, s->d_tallies);
             else if (prof) hipLaunchKernelGGL((k_traverse_wide<true>), dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, (unsigned long long*)(s->d_count + 64) + 16 * (st.wide & 3), nullptr);
-            else hipLaunchKernelGGL((k_traverse_wide<false>), dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, nullptr, nullptr);
+            else {
+                const uint32_t only = s->wide[(size_t)st.wide].only;
+#define WIDE(K) hipLaunchKernelGGL((k_traverse_wide<false, false, K>), dim3(grid), dim3(TRAV_BLOCK), 0, s->stream, d, dw, a, work, nullptr, nullptr)
+                if (only == RT_NODE_TRIANGLES) WIDE(RT_NODE_TRIANGLES);
+                else if (only == RT_NODE_QUADS) WIDE(RT_NODE_QUADS);
+                else if (only == RT_NODE_SPHERES) WIDE(RT_NODE_SPHERES);
+                else WIDE(0);
+#undef WIDE
+            }
         } else if (st.kind == RT_STRETCH_LOCKSTEP) {
 #define LOCKSTEP(C, M) hipLaunchKernelGGL((k_traverse_lockstep<C, M>), dim3(waves), dim3(TRAV_BLOCK), lds, s->stream, d, a, s->d_tallies)
             if (count) LOCKSTEP(true, RT_MEDIA_ANY);  // counting passes need no speed: one instantiation serves all scenes

@@ -63,6 +63,7 @@ struct WideBvh {
     std::vector<double> refbox;   // 6 per level-lambda node
     double base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
     double bounds[6] = {0, 0, 0, 0, 0, 0};  // of everything below the entry (x, y, z: start, end), in its chain
+    uint32_t only = 0;            // the kind of every item's primitives when they are all of one kind, else 0
 };
 namespace wide_detail {
 struct Item { uint32_t kind, first, count; double box[6]; };
@@ -182,6 +183,13 @@ inline bool build_wide_slots(const Ctx& c, const rt_node* nodes, uint32_t root, 
     if (K > RT_WIDE_MAX_K) return false;  // 2 M item slots
     out.entry = root; out.end = nodes[root].skip; out.chain = c.chain; out.K = K; out.lambda = lambda;
     out.leaves = (uint32_t)c.leaves.size();
+    out.only = 0u;
+    {
+        bool first = true, same = true;
+        for (const Leaf& l : c.leaves)
+            for (const Item& it : l.items) { if (first) { out.only = it.kind; first = false; } same = same && it.kind == out.only; }
+        if (!same) out.only = 0u;
+    }
     const double inf = std::numeric_limits<double>::infinity();
     const size_t width = (size_t)1 << (RT_WIDE_LOG * K);
     // every level's boxes first (the grid needs the bounds of the whole tree), then the records
@@ -534,7 +542,7 @@ struct WideKeepsAll {
     RT_HD void fetch_cursor(WLane&) const {}   // pending, rev, slot, level, item_*
     RT_HD void stash_cursor(const WLane&) const {}
 };
-template <bool COUNT, class Away = WideKeepsAll>
+template <bool COUNT, class Away = WideKeepsAll, int ONLY = 0>
 RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tally, const Away& away = Away()) {
     if (ln.kind & 0x200u) {  // lambda = 0: the item is a whole leaf, whose box narrows the interval first
         ln.kind &= ~0x200u;
@@ -551,7 +559,7 @@ RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tal
         if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); away.stash_cursor(ln); return; }
         ln.s = s; ln.e = e;
     }
-    if (ln.k < ln.kend) lane_prim_tests<COUNT>(S, ln, tally);
+    if (ln.k < ln.kend) lane_prim_tests<COUNT, ONLY>(S, ln, tally);
     if (ln.k >= ln.kend) { away.fetch_cursor(ln); wide_ascend(ln, W); away.stash_cursor(ln); }
 }
 
