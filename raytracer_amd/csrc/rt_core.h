@@ -385,6 +385,31 @@ RT_HD bool slab3(const double2 bx, const double2 by, const double2 bz, const Ray
     return true;
 }
 
+// The same without the early exits (for steps a wavefront takes for lanes in different situations, where a lane's exit
+// saves nothing): every axis is worked through, and the three tests AABB::hit makes on the way are combined at the end.
+RT_HD bool slab3_flat(const double2 bx, const double2 by, const double2 bz, const Ray& r, double& s, double& e) {
+    bool ok = true;
+    {
+        const double t0 = (bx.x - r.o.x) * r.inv.x, t1 = (bx.y - r.o.x) * r.inv.x;
+        const bool up = t0 < t1;
+        s = fmax(s, up ? t0 : t1); e = fmin(e, up ? t1 : t0);
+        ok = ok & !(e <= s);
+    }
+    {
+        const double t0 = (by.x - r.o.y) * r.inv.y, t1 = (by.y - r.o.y) * r.inv.y;
+        const bool up = t0 < t1;
+        s = fmax(s, up ? t0 : t1); e = fmin(e, up ? t1 : t0);
+        ok = ok & !(e <= s);
+    }
+    {
+        const double t0 = (bz.x - r.o.z) * r.inv.z, t1 = (bz.y - r.o.z) * r.inv.z;
+        const bool up = t0 < t1;
+        s = fmax(s, up ? t0 : t1); e = fmin(e, up ? t1 : t0);
+        ok = ok & !(e <= s);
+    }
+    return ok;
+}
+
 // Sphere::hit, sphere.rs:40-63 (the part that decides t; the record is rebuilt in finalize()).
 RT_HD bool sphere_t(const double2* sp, const Ray& r, double s, double e, double& t) {
     const double2 a0 = sp[0], a1 = sp[1];

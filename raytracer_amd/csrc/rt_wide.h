@@ -468,6 +468,7 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec, Tally*
         ln.item_kind = k == 1u ? tail.y : ln.item_kind;
         ln.item_counts = k == 1u ? ((unsigned long long)tail.w << 32 | tail.z) : ln.item_counts;
     }
+    bool missed = false;
     if (W.lambda != 0u && k == W.lambda) {  // BVHNode::hit's box test for the leaf (bvh.rs:31-37)
         const double2* rb = W.refbox + 3u * (ln.slot >> (RT_WIDE_LOG * W.lambda));
         const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
@@ -477,8 +478,10 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec, Tally*
 #endif
         double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
         if (tally) tally->node_tests++;
-        if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); return; }
-        ln.s = s; ln.e = e;
+        // (no early exit: a leaf that is missed ends up with no child to visit, below)
+        const bool ok = slab3_flat(b0, b1, b2, ln.cur, s, e);
+        ln.s = ok ? s : ln.s; ln.e = ok ? e : ln.e;
+        missed = !ok;
     }
     if (tally) tally->wide_tests += RT_WIDE;
     const bool inside = k <= W.lambda;
@@ -500,6 +503,15 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec, Tally*
     RT_WIDE_CHILD(6u, q4.z, q4.w, q5.x)
     RT_WIDE_CHILD(7u, q5.y, q5.z, q5.w)
 #undef RT_WIDE_CHILD
+    m = missed ? 0u : m;
+    if (!W.fast) {
+        // The children to visit join those of the nodes above, and the walk goes on with the nearest of them all: the
+        // lowest set bit is this node's first such child when it has one (no bit of a lower level is set while the
+        // cursor stands here), else the next sibling of an ancestor -- one path for both, without a branch.
+        ln.pending |= (unsigned long long)m << (8u * k);
+        wide_ascend(ln, W);
+        return;
+    }
     if (m == 0u) { wide_ascend(ln, W); return; }
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t j = (uint32_t)(__ffs((int)m) - 1);
