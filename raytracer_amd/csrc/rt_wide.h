@@ -568,8 +568,10 @@ RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tal
 #endif
         double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
         if (COUNT) tally.node_tests++;
-        if (!slab3(b0, b1, b2, ln.cur, s, e)) { wide_ascend(ln, W); away.stash_cursor(ln); return; }
-        ln.s = s; ln.e = e;
+        // (no early exit: a leaf that is missed has its run ended here and moves on with the lanes whose runs are over)
+        const bool ok = slab3_flat(b0, b1, b2, ln.cur, s, e);
+        ln.s = ok ? s : ln.s; ln.e = ok ? e : ln.e;
+        ln.k = ok ? ln.k : ln.kend;
     }
     if (ln.k < ln.kend) lane_prim_tests<COUNT, ONLY>(S, ln, tally);
     if (ln.k >= ln.kend) { away.fetch_cursor(ln); wide_ascend(ln, W); away.stash_cursor(ln); }
