@@ -714,11 +714,8 @@ __device__ __forceinline__ bool block_perlin_value(const DScene& S, bool wants, 
 // Material::emitted / scatter on the closest hit, throughput update, termination, and compaction of the
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
-#ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 4
-#endif
 template <bool PLAIN>
-__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : RT_SHADE_WAVES) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
+__global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
                                                        Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
