@@ -302,7 +302,7 @@ def test_bench_line_keeps_its_contract():
         sys.path.insert(0, ROOT)
     import bench
     args = argparse.Namespace(width=120, batch_paths=0, scaling="weak", fast_bvh=False, whole_paths=False, queues=False,
-                              split_bounce=False, no_fast_report=False)
+                              split_bounce=False, no_fast_report=False, fast_report=True)
     for config, spp in (("C2", 16), ("C4", 8)):
         out = bench.measure(args, config, spp, 2, 1, torch, None, 0, 0, 1, False)
         assert out["metric"] == "Mrays/s" and out["unit"] == "Mrays/s" and out["n_gpus"] == 1 and out["steps"] == 2
