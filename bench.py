@@ -215,12 +215,21 @@ def traffic_model(kernel, stats, rays, paths):
         what = "1.25 sectors of 64 B per finished path (path state stays in registers)"
     elif kernel.startswith("traverse phase"):
         lists = float(sum(s.get("list_rays", 0) for s in stats))
-        # first stretch (lockstep, every ray): ray 48 B + stream position 12 B + signature 4 B read, closest hit 16 B written;
-        # each eight-wide launch, per ray of its work list: list entry 4 B, ray 48 B and closest hit 16 B read (gathers),
-        # closest hit 16 B written
-        total = (64.0 + 16.0) * rays + (4.0 + 48.0 + 16.0 + 16.0) * lists
-        what = ("80 B per ray in the stretch every ray goes through + 84 B per work-list entry of the eight-wide launches "
-                f"({lists / rays:.2f} entries per ray); gathers counted at their useful bytes, not at sector granularity")
+        if stats and stats[0].get("shade_quads", 0):
+            # the traverse launches walk the eight-wide trees only (the top level's quads are tested by the shade
+            # launches, which read the ray anyway): per ray of a work list, list entry 4 B, ray 48 B and t of the closest
+            # hit so far 8 B read (gathers), closest hit 16 B written
+            total = (4.0 + 48.0 + 8.0 + 16.0) * lists
+            what = (f"76 B per work-list entry of the eight-wide launches ({lists / rays:.2f} entries per ray; nothing else runs "
+                    "in the traverse phase: the top level's quads are tested in the shade launches); gathers counted at "
+                    "their useful bytes, not at sector granularity")
+        else:
+            # first stretch (lockstep, every ray): ray 48 B + stream position 12 B + signature 4 B read, closest hit 16 B
+            # written; each eight-wide launch, per ray of its work list: list entry 4 B, ray 48 B and closest hit 16 B
+            # read (gathers), closest hit 16 B written
+            total = (64.0 + 16.0) * rays + (4.0 + 48.0 + 16.0 + 16.0) * lists
+            what = ("80 B per ray in the stretch every ray goes through + 84 B per work-list entry of the eight-wide launches "
+                    f"({lists / rays:.2f} entries per ray); gathers counted at their useful bytes, not at sector granularity")
     else:
         return None
     return {"bytes_per_ray": total / rays, "what": what, "rays": rays, "paths": paths}
@@ -322,7 +331,9 @@ def measure(args, config, spp_override, steps, warmup, torch, dist, rank, local_
     if launches > 0 and ms_kernel > 0:
         avg_ms = ms_kernel / launches
         rays_per_launch = rays_local / launches
-        shade = 0.0 if whole else FLOPS_SHADE
+        # (what the shade launches do is not the traverse phase's work: shading, and the top level's quads where those
+        # are left to them -- 60 flops each, as the counting pass prices them in the traverse launches it runs)
+        shade = 0.0 if whole else FLOPS_SHADE + 60.0 * stats[0].get("shade_quads", 0)
         alg = rays_per_launch * (flops_alg - shade) / (avg_ms * 1e-3) / 1e12
         exe = rays_per_launch * (flops_exec - shade) / (avg_ms * 1e-3) / 1e12
         prof = profiled(config)

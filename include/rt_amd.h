@@ -135,10 +135,10 @@ typedef struct rt_render_opts {
     uint32_t flags;       /* RT_FLAG_* */
     uint64_t seed;        /* key of the counter-based generator */
     double background[3]; /* camera.rs:36 */
-    uint64_t batch_paths; /* paths in flight per wavefront batch; 0 = library default: 32 M (scenes without BVH entries)
-                             or 128 M (with), about 270 bytes of workspace each (8.6 / 35 GB, kept by the scene handle
-                             until rt_scene_destroy), never more than a quarter of the device memory free when the
-                             workspace has to grow */
+    uint64_t batch_paths; /* paths in flight per wavefront batch; 0 = library default: 128 M (scenes without BVH entries)
+                             or 256 M (with), about 200 to 410 bytes of workspace each (kept by the scene handle until
+                             rt_scene_destroy), fewer where that workspace would not fit two fifths of the device memory
+                             free when it has to grow */
 } rt_render_opts;
 #define RT_FLAG_COUNTERS 1u /* also count BVH box tests and primitive tests (slower) */
 #define RT_FLAG_NO_CULL 2u  /* ignore the conservative cull boxes: do exactly the tests the reference does */
@@ -151,7 +151,11 @@ typedef struct rt_render_opts {
 #define RT_FLAG_QUEUES 8u      /* always the queue-based schedule */
 #define RT_FLAG_SPLIT_BOUNCE 16u /* queue-based schedule of a scene without BVH entries: one traverse and one shade
                                     launch per bounce, as for scenes with BVH entries, instead of the single bounce
-                                    kernel that does both (the default there).  The film is the same either way */
+                                    kernel that does both (the default there).  For a scene whose top level is a run of
+                                    quads followed by nothing but eight-wide trees (a room around meshes): the quads
+                                    get a traverse launch of their own ahead of the trees', in the list's own order,
+                                    instead of being tested by the shade launches after them (the default there).  The
+                                    film is the same either way */
 
 #define RT_FLAG_FAST_BVH 32u /* NOT the reference's result in every case.  BVH entries whose leaves the library walks
                                 through its own eight-wide tree visit that tree's children nearest first instead of in the
@@ -190,6 +194,9 @@ typedef struct rt_stats {
                             those launches (a ray counts once per tree whose bounds it can reach); 0 where no lists are used */
     uint64_t wide_tests; /* child boxes of the library's eight-wide trees tested (f32; none in the reference), only with
                             RT_FLAG_COUNTERS and the cull boxes on */
+    uint64_t shade_quads; /* quads of the top level that the shade launches test per ray, ahead of shading: a run of quads
+                            that precedes nothing but eight-wide trees (a room around meshes) is left to them, and the
+                            traverse launches then walk the trees only; 0: the traverse launches test everything */
 } rt_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */

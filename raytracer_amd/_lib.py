@@ -56,7 +56,8 @@ class rt_stats(C.Structure):
                 ("ms_total", C.c_double), ("ms_traverse", C.c_double), ("ms_shade", C.c_double),
                 ("ms_paths", C.c_double), ("ms_bounce", C.c_double), ("ms_finish", C.c_double), ("traverse_launches", C.c_uint32),
                 ("path_launches", C.c_uint32), ("bounce_launches", C.c_uint32), ("bounces", C.c_uint32),
-                ("lockstep", C.c_uint32), ("finish_launches", C.c_uint32), ("list_rays", C.c_uint64), ("wide_tests", C.c_uint64)]
+                ("lockstep", C.c_uint32), ("finish_launches", C.c_uint32), ("list_rays", C.c_uint64), ("wide_tests", C.c_uint64),
+                ("shade_quads", C.c_uint64)]
 
 
 RT_FLAG_COUNTERS = 1

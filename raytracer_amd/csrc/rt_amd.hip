@@ -85,14 +85,21 @@ struct Gates {
     uint32_t stride, n;    // n = 0: no gates
     uint32_t init_hits;    // the kernel that makes a ray also writes "no hit" for it (0: the first launch of the
                            // traverse phase visits every ray and starts from nothing by itself)
+    uint32_t tag;          // 1: the ray's gate bits travel in the high bits of its `born` word, and the kernel that makes
+                           // a ray writes t = infinity ("no hit so far") for it if it is in any list at all: every
+                           // launch that walks a list goes on from there and writes a hit only when it finds one
 };
+#define RT_BORN_BITS 20u           // with Gates::tag the iteration a path was generated in takes the low 20 bits of `born`,
+#define RT_BORN_MASK 0xFFFFFu      // the gate bits of its current ray (RT_MAX_GATES <= 12) the rest
 // Appends slot `dst` of every `alive` thread to the lists its ray (o, d) belongs in: ballot + prefix count per wave and
 // list, one atomic per workgroup and list.  Called by all threads of a 256-thread workgroup together.
-__device__ __forceinline__ void gates_append(const Gates& G, bool alive, uint32_t dst, V3 o, V3 d, uint32_t* counts) {
+__device__ __forceinline__ uint32_t gates_of(const Gates& G, bool alive, V3 o, V3 d) {
+    return (G.n != 0u && alive) ? ray_gates(*G.info, o, d) : 0u;
+}
+__device__ __forceinline__ void gates_append(const Gates& G, uint32_t bits, uint32_t dst, uint32_t* counts) {
     __shared__ uint32_t g_wave[4][RT_MAX_GATES];
     __shared__ uint32_t g_base[RT_MAX_GATES];
     if (G.n == 0u) return;
-    const uint32_t bits = alive ? ray_gates(*G.info, o, d) : 0u;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t b = 0; b < G.n; ++b) {
         const unsigned long long mask = __ballot((bits >> b) & 1u);
@@ -108,7 +115,8 @@ __device__ __forceinline__ void gates_append(const Gates& G, bool alive, uint32_
     for (uint32_t b = 0; b < G.n; ++b) {
         const unsigned long long mask = __ballot((bits >> b) & 1u);
         if ((bits >> b) & 1u)
-            G.lists[(size_t)b * G.stride + g_base[b] + g_wave[wave][b] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = dst;
+            G.lists[(size_t)b * G.stride + g_base[b] + g_wave[wave][b] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] =
+                dst;
     }
 }
 
@@ -132,12 +140,14 @@ __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, 
         q.pix[idx] = pixel;
         q.smp[idx] = sample0 + s_local;
         q.slot[idx] = slot0 + j;
-        q.born[idx] = iter;
         q.ctr[idx] = rng.ctr;
         if (Gp->n != 0u) q.sig[idx] = ray_signature(*Gp, o, d);
         if (gates.n && gates.init_hits) { hb.t[idx] = RT_INF; hb.ref[idx] = RT_NO_HIT; }
     }
-    gates_append(gates, alive, idx, o, d, counts);
+    const uint32_t bits = gates_of(gates, alive, o, d);
+    if (alive) q.born[idx] = iter | (gates.tag ? bits << RT_BORN_BITS : 0u);
+    if (gates.tag && bits != 0u) hb.t[idx] = RT_INF;
+    gates_append(gates, bits, idx, counts);
 }
 
 // Where the rays of one launch are.  The queue is a row of regions of `stride` slots: one per signature class (a single
@@ -472,11 +482,12 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
                         const uint32_t mine = pool_next + (uint32_t)__popcll(mask & lt_mask);
                         if (mine < pool_end) {
                             idx = a.wl ? a.wl[mine] : seg_nth(a.segs, mine);
+                            const bool carried = a.resume != 0u;
                             const double tmin = a.tmin ? a.tmin[idx] : 0.001, tmax = a.tmax ? a.tmax[idx] : RT_INF;
                             const Ray w = ray_world(mk(a.q.ox[idx], a.q.oy[idx], a.q.oz[idx]), mk(a.q.dx[idx], a.q.dy[idx], a.q.dz[idx]));
                             // going on from an earlier launch's closest hits: only t of that hit is read, and the
                             // hit is written back only if the tree holds a closer one (the buffer keeps what it has)
-                            Best b0; b0.t = a.resume ? a.hb.t[idx] : RT_INF; b0.ref = a.resume ? RT_REF_CARRIED : RT_NO_HIT; b0.chain = 0u;
+                            Best b0; b0.t = carried ? a.hb.t[idx] : RT_INF; b0.ref = carried ? RT_REF_CARRIED : RT_NO_HIT; b0.chain = 0u;
                             wide_begin(ln, S, W, w, tmin, tmax, b0);
                             away.stash_all(ln);
                         }
@@ -714,12 +725,28 @@ __device__ __forceinline__ bool block_perlin_value(const DScene& S, bool wants, 
 // Material::emitted / scatter on the closest hit, throughput update, termination, and compaction of the
 // surviving paths into the next queue (camera.rs:349-408 unrolled into a loop).  A path that ends writes its
 // radiance once into lum[] at its batch index.
-template <bool PLAIN>
+// WALLS (trees whose top level is a run of quads followed by eight-wide trees, see rt_scene::walls): the launches
+// before this one have walked the trees only, for the rays whose gate bits say they can reach one, and left the closest
+// hit there in `hb`; the quads of entries [walls.first, walls.end) -- which the reference's list scan visits FIRST
+// (hittable_list.rs:88-102) -- are tested here, where the ray is in registers anyway, through scalar loads like the
+// lockstep walk's.  Why the order does not show in the result: in the list's order the trees come after the quads and
+// are handed (tmin, t_quad), t_quad the closest quad's parameter.  The trees hold primitives that test a half-open
+// interval only (triangles, spheres: triangle.rs:131, sphere.rs:55; rt_scene::walls is not set otherwise), so under
+// that cap a tree reports its closest hit below t_quad if it has one, and nothing else: a leaf's primitives are offered
+// (s, min(e, cap, closest so far)) with (s, e) the leaf box's interval (bvh.rs:31-37), a hit at s <= t < min(e, cap)
+// passes whether the cap is there or not, and the leaf is entered for it either way (s <= t < cap leaves the capped
+// interval non-empty).  Walked without the cap, a tree reports its closest hit t_tree whatever t_quad is; that hit
+// replaces the quad's exactly when t_tree < t_quad.  (Trees of quads are another matter: those test a closed interval,
+// parallelogram.rs:101-103, and whether a hit AT the cap passes depends on the leaf box's interval being non-empty
+// under the cap, which the hit's parameter alone does not tell.)
+struct Walls { uint32_t first, end; };
+template <bool PLAIN, bool WALLS = false>
 __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
                                                        Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
-                                                       uint32_t iter, uint32_t max_depth, Gates gates, HitBuf hb_out) {
+                                                       uint32_t iter, uint32_t max_depth, Gates gates, HitBuf hb_out,
+                                                       Walls walls) {
     __shared__ uint32_t wave_total[SHADE_BLOCK / 64][4];
     __shared__ uint32_t block_base[4];
     uint32_t n;
@@ -737,15 +764,37 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         slot = q.slot[idx];
         born = q.born[idx];
         beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
-        uint32_t ref = hb.ref[idx];
-        if (ref == RT_NO_HIT) {
+        Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0u;
+        Ray w = ray_world(mk(0, 0, 0), mk(1, 1, 1));
+        if constexpr (WALLS) {
+            const uint32_t reached = born >> RT_BORN_BITS;  // the gate bits of this ray: which trees' launches have seen it
+            born &= RT_BORN_MASK;
+            w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
+            if (reached != 0u) {
+                b.t = hb.t[idx];
+                if (b.t < RT_INF) { b.ref = hb.ref[idx]; b.chain = hb.chain[idx]; }  // (still infinity: no tree was hit)
+            }
+            Best bw; bw.t = RT_INF; bw.ref = RT_NO_HIT; bw.chain = 0u;
+            Tally unused = tally_zero();
+            for (uint32_t i = walls.first; i < walls.end; ++i) {  // (the same entries for every lane: scalar loads)
+                const Node nu = load_node(S, i);
+                run_prims<false, true>(S, RT_NODE_QUADS, nu.first, nu.count, 0u, w, 0.001, fmin(RT_INF, bw.t), bw, unused);
+            }
+            const bool tree_wins = b.ref != RT_NO_HIT && b.t < bw.t;
+            b.t = tree_wins ? b.t : bw.t; b.ref = tree_wins ? b.ref : bw.ref; b.chain = tree_wins ? b.chain : bw.chain;
+        } else {
+            b.ref = hb.ref[idx];
+        }
+        if (b.ref == RT_NO_HIT) {
             lum_r[3u * (size_t)slot] = beta.x * bgr; lum_g[3u * (size_t)slot] = beta.y * bgg; lum_b[3u * (size_t)slot] = beta.z * bgb;
         } else {
             pix = q.pix[idx];
             smp = q.smp[idx];
             ctr = q.ctr[idx];
-            Ray w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
-            Best b; b.t = hb.t[idx]; b.ref = ref; b.chain = hb.chain[idx];
+            if constexpr (!WALLS) {
+                w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
+                b.t = hb.t[idx]; b.chain = hb.chain[idx];
+            }
             rec = finalize<false, PLAIN>(S, w, b);
             m = S.mats[rec.mat];
             wd = w.d;
@@ -801,12 +850,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         out.ox[dst] = no.x; out.oy[dst] = no.y; out.oz[dst] = no.z;
         out.dx[dst] = nd.x; out.dy[dst] = nd.y; out.dz[dst] = nd.z;
         out.br[dst] = beta.x; out.bg[dst] = beta.y; out.bb[dst] = beta.z;
-        out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot; out.born[dst] = born;
+        out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot;
         out.ctr[dst] = ctr;
         if (Gp->n != 0u) out.sig[dst] = sig;
         if (gates.n && gates.init_hits) { hb_out.t[dst] = RT_INF; hb_out.ref[dst] = RT_NO_HIT; }
     }
-    gates_append(gates, alive, dst, no, nd, out_count);
+    // (the gate bits last: by now the new ray is all that is left in registers)
+    const uint32_t bits = gates_of(gates, alive, no, nd);
+    if (alive) out.born[dst] = born | (gates.tag ? bits << RT_BORN_BITS : 0u);
+    if (gates.tag && bits != 0u) hb_out.t[dst] = RT_INF;
+    gates_append(gates, bits, dst, out_count);
 }
 
 // One whole bounce for trees WITHOUT BVH entries: the lockstep walk of k_traverse_lockstep followed, in the same
@@ -924,7 +977,7 @@ template <bool LOCKSTEP, int MEDIA, bool PLAIN>
 __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
     DScene S, uint64_t seed, Segs segs, Queue q, double* lum_r, double* lum_g, double* lum_b, double bgr, double bgg,
     double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters, const Stretch* stretches,
-    uint32_t n_stretch, const DWide* wides, uint32_t fast, uint32_t* work) {
+    uint32_t n_stretch, const DWide* wides, uint32_t fast, uint32_t* work, uint32_t born_mask) {
     Levels L; L.base = g_levels + threadIdx.x; L.stride = blockDim.x;
     Tally tally = tally_zero();
     const uint32_t lane = threadIdx.x & 63u;
@@ -954,7 +1007,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
                     const uint32_t idx = seg_nth_all(segs, mine);
                     o = mk(q.ox[idx], q.oy[idx], q.oz[idx]); d = mk(q.dx[idx], q.dy[idx], q.dz[idx]);
                     beta = mk(q.br[idx], q.bg[idx], q.bb[idx]);
-                    pix = q.pix[idx]; smp = q.smp[idx]; slot = q.slot[idx]; born = q.born[idx]; ctr = q.ctr[idx];
+                    pix = q.pix[idx]; smp = q.smp[idx]; slot = q.slot[idx]; born = q.born[idx] & born_mask; ctr = q.ctr[idx];
                     it = iter;
                     alive = true;
                 }
@@ -1169,6 +1222,10 @@ struct rt_scene {
     std::vector<DWide> d_wide;     // on the device
     const Stretch* dev_stretches = nullptr;  // the two vectors above in device memory, for the tail kernel
     const DWide* dev_wides = nullptr;
+    // Top level = one run (or several) of quads in the world's own frame, then nothing but eight-wide trees of triangles
+    // or spheres: a render then walks the trees first and tests the quads inside the shade kernel (k_shade's WALLS
+    // form), which saves the launch that would read every ray for those few quads.
+    bool walls = false;
     GateInfo gate;                 // one gate per wide tree (the first RT_MAX_GATES of them): wide tree w has gate w
     const GateInfo* d_gate = nullptr;
     int media_mode = RT_MEDIA_NONE;  // RT_MEDIA_FLAT when every medium's boundary is plain primitives, else RT_MEDIA_ANY
@@ -1448,6 +1505,24 @@ static int validate(rt_scene* s) {
         s->wide.push_back(std::move(w));
         return (int)s->wide.size() - 1;
     });
+    s->walls = false;
+    if (s->has_bvh && s->stretches.size() >= 2 && s->stretches[0].kind == RT_STRETCH_LOCKSTEP && s->wide.size() <= RT_MAX_GATES) {
+        bool ok = true;
+        uint32_t quads = 0;
+        for (uint32_t i = s->stretches[0].first; i < s->stretches[0].end; ++i) {
+            const rt_node& n = s->nodes[i];
+            ok = ok && n.kind == RT_NODE_QUADS && n.level == 0 && n.chain == 0;
+            quads += n.count;
+        }
+        ok = ok && quads <= 64u;  // (a long list of quads is work worth a launch of its own)
+        for (size_t k = 1; k < s->stretches.size() && ok; ++k) {
+            const Stretch& st = s->stretches[k];
+            ok = st.kind == RT_STRETCH_WIDE && st.wide >= 0;
+            // primitives that test a half-open interval only (see k_shade)
+            if (ok) ok = s->wide[(size_t)st.wide].only == RT_NODE_TRIANGLES || s->wide[(size_t)st.wide].only == RT_NODE_SPHERES;
+        }
+        s->walls = ok;
+    }
     return RT_OK;
 }
 
@@ -1648,13 +1723,15 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 
 // One traverse+intersect launch over the rays of `a` on the scene's stream.
 // `n_upper`: no fewer rays than the launch will find (it sizes the grid; the kernels read the true numbers themselves).
-static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool nocull, uint32_t n_upper, uint32_t* work = nullptr) {
+// k0: the first stretch to walk (1 when the quads of stretch 0 are left to the shade kernel, see rt_scene::walls)
+static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool nocull, uint32_t n_upper, uint32_t* work = nullptr,
+                           size_t k0 = 0) {
     if (!work) work = s->d_count + 4;  // the counter the per-lane kernels hand rays out with
     DScene d = s->d;
     if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
     // every stretch of the queue starts a workgroup of its own
     const uint32_t waves = (n_upper + TRAV_BLOCK - 1) / TRAV_BLOCK + (a_.segs.in_count ? a_.segs.nclass + 1u : 0u);
-    for (size_t k = 0; k < s->stretches.size(); ++k) {
+    for (size_t k = k0; k < s->stretches.size(); ++k) {
         const Stretch& st = s->stretches[k];
         TravArgs a = a_;
         a.first = st.first; a.end = st.end; a.resume = (k > 0 || a_.resume) ? 1u : 0u;
@@ -2014,9 +2091,13 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         // a first stretch that goes to the lockstep kernel visits every ray: it starts from "no hit" itself, and the
         // kernels that make the rays need not write that
         const bool first_fresh = s->stretches[0].kind == RT_STRETCH_LOCKSTEP;
+        // the trees first, the quads of stretch 0 inside the shade kernel (counting passes keep the list's own order)
+        const bool walls = gated && s->walls && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
+        if (walls) for (uint32_t i = s->stretches[0].first; i < s->stretches[0].end; ++i) st.shade_quads += s->nodes[i].count;
         if (gated) {
             gates.info = s->d_gate; gates.lists = s->wl; gates.stride = (uint32_t)s->ws_paths; gates.n = s->gate.n;
-            gates.init_hits = first_fresh ? 0u : 1u;
+            gates.init_hits = (first_fresh || walls) ? 0u : 1u;
+            gates.tag = walls ? 1u : 0u;
         }
         HitBuf hb_in = s->hb, hb_out = gated ? s->hb2 : s->hb;
         auto batch_samples = [&](uint32_t b) { return std::min(spb, o->spp_count - b * spb); };
@@ -2056,6 +2137,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
             return RT_OK;
         };
         for (uint32_t iter = 0;; ++iter) {
+            if (iter > RT_BORN_MASK) return fail(RT_ERR_LIMIT, "more than %u iterations", RT_BORN_MASK);
             if (iter >= RT_LAG && consumed + RT_LAG <= iter && (rc = consume())) return rc;
             // no more rays than this can be waiting: the last exact count plus the camera rays generated since
             uint64_t upper = known_out;
@@ -2117,7 +2199,8 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
 #define FINISH_ARGS d, o->seed, segs, qin, s->lum_r, s->lum_g, s->lum_b, o->background[0], o->background[1], \
                     o->background[2], iter, o->max_depth, (unsigned long long*)(s->d_count + 8), s->dev_stretches, \
                     (uint32_t)((lockstep || nocull) ? 0u : s->stretches.size()), s->dev_wides, \
-                    (uint32_t)(((o->flags & RT_FLAG_FAST_BVH) || s->fast_bvh) ? 1u : 0u), s->d_count + 4
+                    (uint32_t)(((o->flags & RT_FLAG_FAST_BVH) || s->fast_bvh) ? 1u : 0u), s->d_count + 4, \
+                    (gates.tag ? RT_BORN_MASK : 0xFFFFFFFFu)
 #define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(fblock), \
                                             levels_lds(s, fblock), sm, FINISH_ARGS)
                 if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
@@ -2164,13 +2247,19 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                     ta.list_total = (unsigned long long*)(s->d_count + 16);
                 }
                 ta.fast = (o->flags & RT_FLAG_FAST_BVH) ? 1u : 0u;
-                if ((rc = launch_traverse(s, ta, count, nocull, upper_in))) return rc;
+                if (walls) ta.resume = 1u;  // (from t = infinity, written where the ray was made)
+                if ((rc = launch_traverse(s, ta, count, nocull, upper_in, nullptr, walls ? 1 : 0))) return rc;
                 HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
                 const uint32_t sblocks = (upper_in + SHADE_BLOCK - 1) / SHADE_BLOCK + nclass + 1u;
 #define SHADE_ARGS s->d, s->d_sig, o->seed, segs, qin, hb_in, qout, out_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
-                   o->background[1], o->background[2], iter, o->max_depth, gates, hb_out
-                if (s->plain) hipLaunchKernelGGL(k_shade<true>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
-                else hipLaunchKernelGGL(k_shade<false>, dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+                   o->background[1], o->background[2], iter, o->max_depth, gates, hb_out, wl
+                Walls wl;
+                wl.first = s->stretches[0].first; wl.end = s->stretches[0].end;
+                if (walls) {
+                    if (s->plain) hipLaunchKernelGGL((k_shade<true, true>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+                    else hipLaunchKernelGGL((k_shade<false, true>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+                } else if (s->plain) hipLaunchKernelGGL((k_shade<true, false>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+                else hipLaunchKernelGGL((k_shade<false, false>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
 #undef SHADE_ARGS
             }
             HIP_TRY(hipEventRecord(s->ring_ev[r][2], sm));
@@ -2425,7 +2514,7 @@ static int rt_render_multi_impl(const rt_scene* const* scenes, int n, const rt_c
             t.finish_launches += a.finish_launches;
             t.traverse_launches += a.traverse_launches; t.path_launches += a.path_launches;
             t.bounce_launches += a.bounce_launches;
-            t.bounces = std::max(t.bounces, a.bounces); t.lockstep = a.lockstep;
+            t.bounces = std::max(t.bounces, a.bounces); t.lockstep = a.lockstep; t.shade_quads = a.shade_quads;
         }
         *stats = t;
     }

@@ -151,6 +151,7 @@ pub struct RtStats {
     pub finish_launches: u32,
     pub list_rays: u64,
     pub wide_tests: u64,
+    pub shade_quads: u64,
 }
 
 #[link(name = "rt_amd")]

@@ -289,6 +289,78 @@ def test_full_resolution_bvh_scene_properties():
         assert np.array_equal(film, again)
         no_cull, st_nc = scene.render(cam, 20, spec.max_depth, spec.background, cull=False, batch_paths=5_000_000)
         assert np.array_equal(film, no_cull) and st_nc["rays"] == st["rays"]
+        # the room's six quads are tested by the shade launches, after the meshes' trees; on request they get a launch of
+        # their own ahead of the trees, which is the list's own order: the same film
+        assert st["shade_quads"] == 6 and st_nc["shade_quads"] == 0  # (without cull boxes: no work lists, the list's order)
+        in_order, st_o = scene.render(cam, 20, spec.max_depth, spec.background, split_bounce=True)
+        assert st_o["shade_quads"] == 0 and np.array_equal(film, in_order) and st_o["rays"] == st["rays"]
+    finally:
+        scene.close()
+
+
+def _room_with_a_tree(b, kind):
+    """A lit room of six quads, then one BVH: of boxes standing on the floor (their bottom faces lie in the floor's plane:
+    a ray from below meets floor and face at exactly the same parameter) or of triangles lying in that plane."""
+    white = b.mat_lambertian(b.tex_solid(0.73, 0.73, 0.73))
+    red = b.mat_lambertian(b.tex_solid(0.65, 0.05, 0.05))
+    light = b.mat_diffuse_light(b.tex_solid(7.0, 7.0, 7.0))
+    world = b.list_new()
+    b.list_add(world, b.quad((0.0, 0.0, 0.0), (8.0, 0.0, 0.0), (0.0, 0.0, 8.0), white))      # floor, y = 0
+    b.list_add(world, b.quad((0.0, 8.0, 0.0), (8.0, 0.0, 0.0), (0.0, 0.0, 8.0), white))      # ceiling
+    b.list_add(world, b.quad((0.0, 0.0, 8.0), (8.0, 0.0, 0.0), (0.0, 8.0, 0.0), white))      # back
+    b.list_add(world, b.quad((0.0, 0.0, 0.0), (0.0, 8.0, 0.0), (0.0, 0.0, 8.0), red))        # left
+    b.list_add(world, b.quad((8.0, 0.0, 0.0), (0.0, 8.0, 0.0), (0.0, 0.0, 8.0), red))        # right
+    b.list_add(world, b.quad((3.0, 7.5, 3.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), light))
+    inner = b.list_new()
+    rs = np.random.RandomState(5)
+    for i in range(40):
+        x, z = 0.5 + (i % 7), 0.5 + (i // 7)
+        if kind == "boxes":
+            b.list_add(inner, b.slice(b.box((x, 0.0, z), (x + 0.5, float(rs.uniform(0.5, 3.0)), z + 0.5), red)))
+        else:
+            b.list_add(inner, b.triangle((x, 0.0, z), (0.75, 0.0, 0.0), (0.0, 0.0, 0.75), red))
+            b.list_add(inner, b.triangle((x, float(rs.uniform(0.5, 3.0)), z), (0.75, 0.0, 0.0), (0.0, 0.5, 0.75), white))
+    b.list_add(world, b.bvh(inner))
+    b.set_world(b.slice(world))
+
+
+@pytest.mark.parametrize("kind", ["boxes", "triangles"])
+def test_quads_ahead_of_trees_tested_after_them_give_the_list_order_result(kind):
+    """Where a run of quads precedes nothing but eight-wide trees of triangles (or spheres), a render walks the trees
+    first and tests the quads inside the shade launches.  The closest hit does not depend on the order except between
+    hits at exactly equal parameters, which the reference's list order decides (hittable_list.rs:88-102): the trees are
+    handed (tmin, t of the closest quad), a triangle tests a half-open interval (triangle.rs:131), so the quad keeps a
+    tie.  Trees of quads stay in the list's order: parallelogram.rs:101-103 tests a closed interval, and a hit at the
+    cap passes or not with the leaf box's interval (here it does not: the boxes' bottom faces lie in the plane of their
+    BVH boxes, where the reference loses them).  Seen from below the floor, camera rays meet the floor and a box's
+    bottom face, or a triangle lying in the floor, at exactly the same parameter; the films of both schedules agree bit
+    for bit and with the oracle's."""
+    from raytracer_amd import HostBuilder
+    from oracle import oracle as orc
+    from raytracer_amd.builder import camera_new as host_camera_new
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    _room_with_a_tree(hb, kind)
+    _room_with_a_tree(ob, kind)
+    camera = dict(aspect_ratio=1.0, vfov=60.0, defocus_angle=0.0, focus_distance=10.0, look_from=(4.0, -6.0, 4.0),
+                  look_at=(4.0, 0.0, 4.5), view_up=(0.0, 0.0, 1.0))
+    hc, oc = host_camera_new(image_width=96, **camera), orc.camera_new(image_width=96, **camera)
+    bg = (0.1, 0.1, 0.1)
+    scene = hb.commit(0)
+    try:
+        film, st = scene.render(hc, 4, 8, bg)
+        in_order, st_o = scene.render(hc, 4, 8, bg, split_bounce=True)
+        assert st["shade_quads"] == (6 if kind == "triangles" else 0) and st_o["shade_quads"] == 0
+        assert np.array_equal(film, in_order) and st["rays"] == st_o["rays"]
+        want, _ = ob.render(oc, 4, 8, bg)
+        assert np.isclose(film, want, rtol=1e-9, atol=1e-12).all(axis=2).mean() > 0.995
+        # the ties are there: camera rays from below that hit the floor's plane where a tree's primitive lies in it too
+        n = 4000
+        rs = np.random.RandomState(3)
+        o = np.column_stack([rs.uniform(0.5, 7.0, n), np.full(n, -6.0), rs.uniform(0.5, 6.0, n)])
+        d = np.tile([0.0, 1.0, 0.0], (n, 1))
+        got, ref = scene.intersect(o, d, 0.001, np.inf), ob.intersect(o, d, 0.001, np.inf)
+        assert np.array_equal(got["prim"], ref["prim"]) and np.array_equal(got["t"], ref["t"])
+        assert (ref["t"] == 6.0).all() and (ref["prim"] < 6).all()  # the floor keeps every tie
     finally:
         scene.close()
 
