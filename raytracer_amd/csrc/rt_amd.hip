@@ -55,7 +55,9 @@ static hipError_t rt_hip_malloc(T** p, size_t bytes) { return rt_hip_malloc(rein
 
 // ------------------------------------------------------------------------------------------------ kernels
 #define TRAV_BLOCK 64    // one wavefront per workgroup: no barriers, LDS interval slots per lane
+#ifndef SHADE_BLOCK
 #define SHADE_BLOCK 256
+#endif
 
 // Path state queue, SoA: consecutive lanes read consecutive elements of every array.
 struct Queue {
@@ -97,7 +99,7 @@ __device__ __forceinline__ uint32_t gates_of(const Gates& G, bool alive, V3 o, V
     return (G.n != 0u && alive) ? ray_gates(*G.info, o, d) : 0u;
 }
 __device__ __forceinline__ void gates_append(const Gates& G, uint32_t bits, uint32_t dst, uint32_t* counts) {
-    __shared__ uint32_t g_wave[4][RT_MAX_GATES];
+    __shared__ uint32_t g_wave[16][RT_MAX_GATES];  // (workgroups of up to 1024 threads)
     __shared__ uint32_t g_base[RT_MAX_GATES];
     if (G.n == 0u) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -108,7 +110,7 @@ __device__ __forceinline__ void gates_append(const Gates& G, uint32_t bits, uint
     __syncthreads();
     if (threadIdx.x < G.n) {
         uint32_t tot = 0;
-        for (int k = 0; k < 4; ++k) { const uint32_t c = g_wave[k][threadIdx.x]; g_wave[k][threadIdx.x] = tot; tot += c; }
+        for (uint32_t k = 0; k < blockDim.x / 64u; ++k) { const uint32_t c = g_wave[k][threadIdx.x]; g_wave[k][threadIdx.x] = tot; tot += c; }
         g_base[threadIdx.x] = tot ? atomicAdd(counts + RT_COUNT_STRIDE * (4u + threadIdx.x), tot) : 0u;
     }
     __syncthreads();
@@ -158,7 +160,8 @@ __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, 
 // in_count = null: one stretch, slots 0 .. n - 1 (caller-supplied batches).
 #define RT_RING 4            // counter sets in rotation: the host queues launches RT_LAG iterations ahead of the counts it has read
 #define RT_LAG 2
-#define RT_RING_WORDS ((4u + RT_MAX_GATES) * RT_COUNT_STRIDE)  // class counters, then work-list lengths
+#define RT_RING_WORDS ((5u + RT_MAX_GATES) * RT_COUNT_STRIDE)  // class counters, work-list lengths, hits left to the second shade launch
+#define RT_DEFER_WORD ((4u + RT_MAX_GATES) * RT_COUNT_STRIDE)
 struct Segs {
     const uint32_t* __restrict__ in_count;
     uint32_t n;
@@ -740,18 +743,41 @@ __device__ __forceinline__ bool block_perlin_value(const DScene& S, bool wants, 
 // parallelogram.rs:101-103, and whether a hit AT the cap passes depends on the leaf box's interval being non-empty
 // under the cap, which the hit's parameter alone does not tell.)
 struct Walls { uint32_t first, end; };
-template <bool PLAIN, bool WALLS = false>
+// MODE (scenes whose materials are not all plain, i.e. Lambertian / DiffuseLight / Isotropic over a solid colour): a
+// wavefront of the full-material code pays for every material and texture any of its 64 hits has, and keeps too many
+// registers to hide the dependent loads of the hit record.  Where most hits ARE on plain materials, the shade phase of a
+// bounce is two launches instead: MODE 1, the plain code over every ray, which leaves a hit on any other material
+// alone and notes its queue slot in `defer_list` (their number in *defer_count); then MODE 2, the full code over that
+// list.  Both append the rays that go on to the same queue through the same counters; which launch a path was shaded by
+// shows nowhere in its radiance.  MODE 0: one launch does everything.
+#define RT_SHADE_ALL 0
+#define RT_SHADE_PLAIN_DEFER 1
+#define RT_SHADE_DEFERRED 2
+template <bool PLAIN, bool WALLS = false, int MODE = RT_SHADE_ALL>
 __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, const SigInfo* __restrict__ Gp, uint64_t seed,
                                                        Segs segs, Queue q, HitBuf hb,
                                                        Queue out, uint32_t* out_count, double* lum_r, double* lum_g,
                                                        double* lum_b, double bgr, double bgg, double bgb,
                                                        uint32_t iter, uint32_t max_depth, Gates gates, HitBuf hb_out,
-                                                       Walls walls) {
+                                                       Walls walls, uint32_t* defer_list, uint32_t* defer_count) {
+    static_assert(MODE == RT_SHADE_ALL || PLAIN == (MODE == RT_SHADE_PLAIN_DEFER), "plain code defers, full code takes the deferred");
     __shared__ uint32_t wave_total[SHADE_BLOCK / 64][4];
     __shared__ uint32_t block_base[4];
-    uint32_t n;
-    const uint32_t idx = seg_slot(segs, n);
-    bool alive = false;
+    __shared__ uint32_t defer_wave[SHADE_BLOCK / 64];
+    __shared__ uint32_t defer_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t n, idx;
+    if constexpr (MODE == RT_SHADE_DEFERRED) {
+        // (the grid is sized for every ray of the bounce; the workgroups past the end of the list leave at once)
+        const uint32_t listed = *defer_count, base = blockIdx.x * SHADE_BLOCK;
+        if (base >= listed) return;
+        const bool mine = base + threadIdx.x < listed;
+        idx = mine ? defer_list[base + threadIdx.x] : 0u;
+        n = mine ? idx + 1u : idx;
+    } else {
+        idx = seg_slot(segs, n);
+    }
+    bool alive = false, deferred = false;
     V3 no = mk(0, 0, 0), nd = mk(0, 0, 0), beta = mk(0, 0, 0);
     uint32_t pix = 0, smp = 0, slot = 0, born = 0, ctr = 0;
     bool hit = false;
@@ -799,6 +825,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
             m = S.mats[rec.mat];
             wd = w.d;
             hit = true;
+            if constexpr (MODE == RT_SHADE_PLAIN_DEFER) {
+                deferred = !material_is_plain(S, m);  // not for this code: the launch after this one takes it
+                hit = !deferred;
+            }
         }
     }
     // all threads of the workgroup are back together here, which the deferred textures and the shared rejection loop need
@@ -826,16 +856,20 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         }
     }
     // compaction by signature class (one class unless the queues are sorted): ballot + prefix count per wave and
-    // class, one atomic per workgroup and class
+    // class, one atomic per workgroup and class; the hits left to the next launch likewise, into its list
     uint32_t sig = 0xFFFFFFFFu;
     if (alive) sig = ray_signature(*Gp, no, nd);
     const uint32_t cls = sig & (segs.nclass - 1u);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t prefix = 0;
+    uint32_t prefix = 0, defer_prefix = 0;
     for (uint32_t c = 0; c < segs.nclass; ++c) {
         const unsigned long long mask = __ballot(alive && cls == c);
         if (cls == c) prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         if (lane == 0) wave_total[wave][c] = (uint32_t)__popcll(mask);
+    }
+    if constexpr (MODE == RT_SHADE_PLAIN_DEFER) {
+        const unsigned long long mask = __ballot(deferred);
+        defer_prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) defer_wave[wave] = (uint32_t)__popcll(mask);
     }
     __syncthreads();
     if (threadIdx.x < segs.nclass) {
@@ -843,7 +877,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         for (int k = 0; k < SHADE_BLOCK / 64; ++k) { uint32_t c = wave_total[k][threadIdx.x]; wave_total[k][threadIdx.x] = tot; tot += c; }
         block_base[threadIdx.x] = tot ? atomicAdd(out_count + RT_COUNT_STRIDE * threadIdx.x, tot) : 0u;
     }
+    if constexpr (MODE == RT_SHADE_PLAIN_DEFER) {
+        if (threadIdx.x == 64u) {
+            uint32_t tot = 0;
+            for (int k = 0; k < SHADE_BLOCK / 64; ++k) { uint32_t c = defer_wave[k]; defer_wave[k] = tot; tot += c; }
+            defer_base = tot ? atomicAdd(defer_count, tot) : 0u;
+        }
+    }
     __syncthreads();
+    if constexpr (MODE == RT_SHADE_PLAIN_DEFER) {
+        if (deferred) defer_list[defer_base + defer_wave[wave] + defer_prefix] = idx;
+    }
     uint32_t dst = 0u;
     if (alive) {
         dst = cls * segs.stride + block_base[cls] + wave_total[wave][cls] + prefix;
@@ -2091,6 +2135,14 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         // a first stretch that goes to the lockstep kernel visits every ray: it starts from "no hit" itself, and the
         // kernels that make the rays need not write that
         const bool first_fresh = s->stretches[0].kind == RT_STRETCH_LOCKSTEP;
+        // Two shade launches per bounce (k_shade's MODE) where some materials are plain and some are not -- as long as
+        // the hits on the others stay few: the host sees how many there were a few iterations late, and goes back to
+        // one launch for everything when more than a third of a bounce's rays were left to the second.
+        bool any_plain = false;
+        for (const rt_material& m : s->mats)
+            any_plain = any_plain || ((m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC) &&
+                                      s->texs[m.texture].kind == RT_TEX_SOLID);
+        bool two_shades = !lockstep && !s->plain && any_plain && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
         // the trees first, the quads of stretch 0 inside the shade kernel (counting passes keep the list's own order)
         const bool walls = gated && s->walls && !count && !(o->flags & RT_FLAG_SPLIT_BOUNCE);
         if (walls) for (uint32_t i = s->stretches[0].first; i < s->stretches[0].end; ++i) st.shade_quads += s->nodes[i].count;
@@ -2121,6 +2173,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
             if (n_in) last_busy = j + 1u;
             known_out = 0;
             for (uint32_t c = 0; c < nclass; ++c) known_out += s->h_ring[rn * RT_RING_WORDS + RT_COUNT_STRIDE * c];
+            if (two_shades && n_in >= 4096u && (uint64_t)s->h_ring[rn * RT_RING_WORDS + RT_DEFER_WORD] * 3u > n_in) two_shades = false;
             float ms = 0;
             if (bounce) {
                 HIP_TRY(hipEventElapsedTime(&ms, s->ring_ev[r][0], s->ring_ev[r][2]));
@@ -2252,14 +2305,22 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
                 const uint32_t sblocks = (upper_in + SHADE_BLOCK - 1) / SHADE_BLOCK + nclass + 1u;
 #define SHADE_ARGS s->d, s->d_sig, o->seed, segs, qin, hb_in, qout, out_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
-                   o->background[1], o->background[2], iter, o->max_depth, gates, hb_out, wl
+                   o->background[1], o->background[2], iter, o->max_depth, gates, hb_out, wl, qin.sig, out_count + RT_DEFER_WORD
+#define SHADE(P, W, M, G) hipLaunchKernelGGL((k_shade<P, W, M>), dim3(G), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS)
                 Walls wl;
                 wl.first = s->stretches[0].first; wl.end = s->stretches[0].end;
-                if (walls) {
-                    if (s->plain) hipLaunchKernelGGL((k_shade<true, true>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
-                    else hipLaunchKernelGGL((k_shade<false, true>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
-                } else if (s->plain) hipLaunchKernelGGL((k_shade<true, false>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
-                else hipLaunchKernelGGL((k_shade<false, false>), dim3(sblocks), dim3(SHADE_BLOCK), 0, sm, SHADE_ARGS);
+                if (s->plain) {
+                    if (walls) SHADE(true, true, RT_SHADE_ALL, sblocks); else SHADE(true, false, RT_SHADE_ALL, sblocks);
+                } else if (two_shades) {
+                    // plain materials first, the hits on the others noted in a list (the input queue's signature array:
+                    // trees with BVH entries keep no signatures) for the full code
+                    const uint32_t dblocks = sblocks;
+                    if (walls) { SHADE(true, true, RT_SHADE_PLAIN_DEFER, sblocks); SHADE(false, true, RT_SHADE_DEFERRED, dblocks); }
+                    else { SHADE(true, false, RT_SHADE_PLAIN_DEFER, sblocks); SHADE(false, false, RT_SHADE_DEFERRED, dblocks); }
+                } else {
+                    if (walls) SHADE(false, true, RT_SHADE_ALL, sblocks); else SHADE(false, false, RT_SHADE_ALL, sblocks);
+                }
+#undef SHADE
 #undef SHADE_ARGS
             }
             HIP_TRY(hipEventRecord(s->ring_ev[r][2], sm));

@@ -1487,6 +1487,11 @@ RT_HD bool scatter_wants_unit_vector(const rt_material& m) {
 RT_HD bool material_wants_texture(const rt_material& m) {
     return m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
 }
+// The materials the PLAIN code below covers: Lambertian, DiffuseLight, Isotropic over a solid colour.
+RT_HD bool material_is_plain(const DScene& S, const rt_material& m) {
+    return (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC) &&
+           S.texs[m.texture].kind == RT_TEX_SOLID;
+}
 // INLINE_PERLIN = false: the caller evaluates perlin textures itself (tex_is_ready for those hits) and this code holds
 // none of their arithmetic.
 template <bool PLAIN = false, bool INLINE_PERLIN = true>
