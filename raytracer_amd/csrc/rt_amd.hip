@@ -55,9 +55,7 @@ static hipError_t rt_hip_malloc(T** p, size_t bytes) { return rt_hip_malloc(rein
 
 // ------------------------------------------------------------------------------------------------ kernels
 #define TRAV_BLOCK 64    // one wavefront per workgroup: no barriers, LDS interval slots per lane
-#ifndef SHADE_BLOCK
 #define SHADE_BLOCK 256
-#endif
 
 // Path state queue, SoA: consecutive lanes read consecutive elements of every array.
 struct Queue {
@@ -99,7 +97,7 @@ __device__ __forceinline__ uint32_t gates_of(const Gates& G, bool alive, V3 o, V
     return (G.n != 0u && alive) ? ray_gates(*G.info, o, d) : 0u;
 }
 __device__ __forceinline__ void gates_append(const Gates& G, uint32_t bits, uint32_t dst, uint32_t* counts) {
-    __shared__ uint32_t g_wave[16][RT_MAX_GATES];  // (workgroups of up to 1024 threads)
+    __shared__ uint32_t g_wave[4][RT_MAX_GATES];
     __shared__ uint32_t g_base[RT_MAX_GATES];
     if (G.n == 0u) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -110,7 +108,7 @@ __device__ __forceinline__ void gates_append(const Gates& G, uint32_t bits, uint
     __syncthreads();
     if (threadIdx.x < G.n) {
         uint32_t tot = 0;
-        for (uint32_t k = 0; k < blockDim.x / 64u; ++k) { const uint32_t c = g_wave[k][threadIdx.x]; g_wave[k][threadIdx.x] = tot; tot += c; }
+        for (int k = 0; k < 4; ++k) { const uint32_t c = g_wave[k][threadIdx.x]; g_wave[k][threadIdx.x] = tot; tot += c; }
         g_base[threadIdx.x] = tot ? atomicAdd(counts + RT_COUNT_STRIDE * (4u + threadIdx.x), tot) : 0u;
     }
     __syncthreads();
