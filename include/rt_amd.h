@@ -155,7 +155,8 @@ typedef struct rt_render_opts {
                                     quads followed by nothing but eight-wide trees (a room around meshes): the quads
                                     get a traverse launch of their own ahead of the trees', in the list's own order,
                                     instead of being tested by the shade launches after them (the default there).  The
-                                    film is the same either way */
+                                    film is the same either way.  Also: one shade launch per bounce for every
+                                    material, where the default is two (plain materials first, the rest from a list) */
 
 #define RT_FLAG_FAST_BVH 32u /* NOT the reference's result in every case.  BVH entries whose leaves the library walks
                                 through its own eight-wide tree visit that tree's children nearest first instead of in the
@@ -178,7 +179,8 @@ typedef struct rt_stats {
                             only with RT_FLAG_COUNTERS */
     double ms_total;     /* device time of the whole call */
     double ms_traverse;  /* summed duration of the traverse+intersect launches (HIP events) */
-    double ms_shade;     /* summed duration of the shade+compact launches */
+    double ms_shade;     /* summed duration of the shade+compact launches (with shade_quads != 0 they also test the top
+                            level's quads; two launches per bounce where a scene mixes plain and other materials) */
     double ms_paths;     /* summed duration of the whole-path launches (scenes without BVH entries) */
     double ms_bounce;    /* summed duration of the bounce launches: traverse, shade and compaction in one kernel
                             (queue-based schedule of scenes without BVH entries) */
