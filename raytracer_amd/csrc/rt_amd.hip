@@ -406,10 +406,13 @@ struct WideAway {
         u[5][lane] = ln.item_first; u[6][lane] = ln.item_kind;
         u[7][lane] = (uint32_t)ln.item_counts; u[8][lane] = (uint32_t)(ln.item_counts >> 32);
     }
+    __device__ __forceinline__ void fetch_grid(WLane& ln) const {
+        ln.ax = f[0][lane]; ln.ay = f[1][lane]; ln.az = f[2][lane]; ln.bx = f[3][lane]; ln.by = f[4][lane]; ln.bz = f[5][lane];
+    }
     __device__ __forceinline__ void fetch_all(WLane& ln) const {
         fetch_ray(ln);
         fetch_cursor(ln);
-        ln.ax = f[0][lane]; ln.ay = f[1][lane]; ln.az = f[2][lane]; ln.bx = f[3][lane]; ln.by = f[4][lane]; ln.bz = f[5][lane];
+        fetch_grid(ln);
     }
     __device__ __forceinline__ void stash_all(const WLane& ln) const {
         stash_cursor(ln);
@@ -1644,6 +1647,7 @@ static int rt_scene_commit_impl(rt_scene* s, int device) {
         dw.refbox = reinterpret_cast<const double2*>(db);
         for (int ax = 0; ax < 3; ++ax) { dw.base[ax] = w.base[ax]; dw.step[ax] = w.step[ax]; }
         dw.K = w.K; dw.lambda = w.lambda; dw.chain = w.chain; dw.fast = 0u;
+        for (int ax = 0; ax < 3; ++ax) dw.slack[ax] = w.slack[ax];
         s->d_wide.push_back(dw);
     }
     if ((rc = upload(s, s->stretches, &s->dev_stretches))) return rc;

@@ -385,6 +385,29 @@ RT_HD bool slab3(const double2 bx, const double2 by, const double2 bz, const Ray
     return true;
 }
 
+// The same arithmetic as a conservative test (the cull boxes, which the reference does not have): the box is passed over
+// only when e < s, NOT when e = s as in AABB::hit.  A quad tests a closed interval (parallelogram.rs:101-103), so with
+// s = e -- a ray that enters its leaf's box at the very parameter of the closest hit so far, as at a corner shared by
+// neighbouring boxes -- a hit at t = s = e is still possible, and by the reference's order a later quad takes such a tie.
+RT_HD bool slab3_cull(const double2 bx, const double2 by, const double2 bz, const Ray& r, double s, double e) {
+    {
+        double t0 = (bx.x - r.o.x) * r.inv.x, t1 = (bx.y - r.o.x) * r.inv.x;
+        if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
+        if (e < s) return false;
+    }
+    {
+        double t0 = (by.x - r.o.y) * r.inv.y, t1 = (by.y - r.o.y) * r.inv.y;
+        if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
+        if (e < s) return false;
+    }
+    {
+        double t0 = (bz.x - r.o.z) * r.inv.z, t1 = (bz.y - r.o.z) * r.inv.z;
+        if (t0 < t1) { s = fmax(s, t0); e = fmin(e, t1); } else { s = fmax(s, t1); e = fmin(e, t0); }
+        if (e < s) return false;
+    }
+    return true;
+}
+
 // The same without the early exits (for steps a wavefront takes for lanes in different situations, where a lane's exit
 // saves nothing): every axis is worked through, and the three tests AABB::hit makes on the way are combined at the end.
 RT_HD bool slab3_flat(const double2 bx, const double2 by, const double2 bz, const Ray& r, double& s, double& e) {
@@ -648,7 +671,8 @@ template <bool COUNT>
 RT_HD bool cull_pass(const DScene& S, uint32_t i, uint32_t at, Ray& cur, double s, double e, Tally& tally) {
     if (COUNT) tally.cull_tests++;
     ray_need_inv(cur);
-    return slab(reinterpret_cast<const double2*>(S.nodes + 8u * i + at), cur, s, e);
+    const double2* b = reinterpret_cast<const double2*>(S.nodes + 8u * i + at);
+    return slab3_cull(b[0], b[1], b[2], cur, s, e);
 }
 
 // A ray's signature: bit b is clear when the LINE the ray lies on cannot touch the cull box of the tree's b-th
@@ -751,7 +775,7 @@ RT_HD bool cull_pass_f32(const DScene& S, uint32_t i, Ray& cur, double s, double
     const float* f = reinterpret_cast<const float*>(S.nodes + 8u * i + 4u);
     double2 cx, cy, cz;
     cx.x = f[0]; cx.y = f[1]; cy.x = f[2]; cy.y = f[3]; cz.x = f[4]; cz.y = f[5];
-    return slab3(cx, cy, cz, cur, s, e);
+    return slab3_cull(cx, cy, cz, cur, s, e);
 }
 
 // BVHNode::hit's box test (bvh.rs:31-37) for the entry `n` at index i: returns the index to go on with.
@@ -1108,10 +1132,9 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
         double bs = s, be = e;
         if (COUNT) { tally.node_tests++; tally.cull_tests++; }
         {
-            double cs = s, ce = e;  // the cull box narrows nothing
-            double2 c0, c1, c2;
+            double2 c0, c1, c2;  // (the cull box narrows nothing)
             c0.x = cf0.x; c0.y = cf0.y; c1.x = cf0.z; c1.y = cf0.w; c2.x = cf1.x; c2.y = cf1.y;
-            if (!slab3(c0, c1, c2, ln.cur, cs, ce)) { ln.i = n.skip; return; }
+            if (!slab3_cull(c0, c1, c2, ln.cur, s, e)) { ln.i = n.skip; return; }
         }
         if (!slab3(b0, b1, b2, ln.cur, bs, be)) { ln.i = n.skip; return; }
         if (n.count != 0u) {
@@ -1130,8 +1153,7 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
     }
     if (n.kind == RT_NODE_CULL) {
         if (COUNT) tally.cull_tests++;
-        double cs = s, ce = e;
-        if (slab3(b0, b1, b2, ln.cur, cs, ce)) { ln.i = ln.i + 1u; return; }
+        if (slab3_cull(b0, b1, b2, ln.cur, s, e)) { ln.i = ln.i + 1u; return; }
         ln.i = n.skip;
         if (tail.w != 0u) {
             // a row of boxes: the record also holds the box of the CULL entry at n.skip (widened to f32), so a miss
@@ -1139,8 +1161,7 @@ RT_HD void lane_node_step(const DScene& S, const Src& src, Lane& ln, const Level
             if (COUNT) tally.cull_tests++;
             double2 c0, c1, c2;
             c0.x = cf0.x; c0.y = cf0.y; c1.x = cf0.z; c1.y = cf0.w; c2.x = cf1.x; c2.y = cf1.y;
-            cs = s; ce = e;
-            ln.i = slab3(c0, c1, c2, ln.cur, cs, ce) ? n.skip + 1u : tail.z;
+            ln.i = slab3_cull(c0, c1, c2, ln.cur, s, e) ? n.skip + 1u : tail.z;
         }
         return;
     }
@@ -1285,10 +1306,8 @@ RT_HD void lane_sub_step(const DScene& S, Lane& ln, Tally& tally) {
         double2 x0, y0, z0, x1, y1, z1;
         x0.x = p.x; x0.y = p.y; y0.x = p.z; y0.y = p.w; z0.x = q.x; z0.y = q.y;
         x1.x = q.z; x1.y = q.w; y1.x = r.x; y1.y = r.y; z1.x = r.z; z1.y = r.w;
-        double cs = ln.s, ce = e;
-        if (slab3(x0, y0, z0, ln.cur, cs, ce)) mask |= 1u << b;
-        cs = ln.s; ce = e;
-        if (slab3(x1, y1, z1, ln.cur, cs, ce)) mask |= 2u << b;
+        if (slab3_cull(x0, y0, z0, ln.cur, ln.s, e)) mask |= 1u << b;
+        if (slab3_cull(x1, y1, z1, ln.cur, ln.s, e)) mask |= 2u << b;
     }
     ln.kind = (ln.kind & 0xFFu) | 0x100u;
     ln.state = RT_ST_RUN;

@@ -42,7 +42,8 @@ struct DWide {               // as the kernels see it
                              // base + q * step of the tree's bounds, starts rounded down and ends up (96 bytes); then
                              // four words: level-1 nodes: the first primitive of the node's first item | bits 0..7 the
                              // items' primitive kind, bits 8..10 the axis along which children 0..3 lie beyond (bit 10:
-                             // before) children 4..7 | the eight items' primitive counts, a byte each (two words).  The
+                             // before) children 4..7, bits 16..23 which items are the six sides of an axis-aligned box in
+                             // create_box's order | the eight items' primitive counts, a byte each (two words).  The
                              // items of a level-1 node are consecutive runs of one array of primitives.
     const double2* refbox;   // per level-lambda node: the reference's box of its leaf, 3 x (start, end)
     double base[3], step[3]; // the grid
@@ -51,6 +52,9 @@ struct DWide {               // as the kernels see it
     uint32_t chain;          // the instance chain the whole tree lives in
     uint32_t fast;           // 1: children are visited nearest first (see wide_node_step); results then differ from the
                              // reference's where two primitives are hit at exactly the same parameter
+    float slack[3];          // per axis, in grid steps: how far an item's box on the grid can reach beyond the geometry
+                             // (the widening of prim_box, the rounding onto the grid, the extra step of either side and
+                             // the f32 evaluation of wide_box); read where a box's sides are chosen (wide_box_pairs)
 };
 RT_HD uint32_t wide_node_index(uint32_t K, uint32_t k, uint32_t g) {
     return (0x49249249u & ((1u << (RT_WIDE_LOG * (K - k))) - 1u)) + g;  // (8^(K-k) - 1) / 7 nodes lie above level k
@@ -64,6 +68,7 @@ struct WideBvh {
     double base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
     double bounds[6] = {0, 0, 0, 0, 0, 0};  // of everything below the entry (x, y, z: start, end), in its chain
     uint32_t only = 0;            // the kind of every item's primitives when they are all of one kind, else 0
+    float slack[3] = {0, 0, 0};   // see DWide
 };
 namespace wide_detail {
 struct Item { uint32_t kind, first, count; double box[6]; };
@@ -102,6 +107,41 @@ inline void prim_box(const Ctx& c, uint32_t kind, uint32_t first, uint32_t count
     }
 }
 inline bool is_run(uint8_t kind) { return kind >= RT_NODE_SPHERES && kind <= RT_NODE_QUADRICS; }
+// Whether quads [first, first + 6) are the six sides of an axis-aligned box in create_box's order
+// (parallelogram.rs:146-195): z = max, x = max, z = min, x = min, y = max, y = min, each side a rectangle with edges
+// along the axes that spans the whole face.  (The walk may then look at the two or four sides a ray can meet first and
+// at the others only if those are missed: wide_box_pairs.)
+inline bool is_reference_box(const double* quads, uint32_t first) {
+    const double inf = std::numeric_limits<double>::infinity();
+    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    for (uint32_t i = 0; i < 6u; ++i) {
+        const double* r = quads + 16 * (size_t)(first + i);
+        for (int j = 0; j < 16; ++j) if (!std::isfinite(r[j])) return false;
+        for (int a = 0; a < 3; ++a) {
+            const double q = r[4 + a], u = r[7 + a], v = r[10 + a];
+            for (double x : {q, q + u, q + v, q + u + v}) { lo[a] = std::min(lo[a], x); hi[a] = std::max(hi[a], x); }
+        }
+    }
+    static const int axis[6] = {2, 0, 2, 0, 1, 1};
+    static const bool upper[6] = {true, true, false, false, true, false};
+    for (uint32_t i = 0; i < 6u; ++i) {
+        const double* r = quads + 16 * (size_t)(first + i);
+        const double *n = r, *q = r + 4, *u = r + 7, *v = r + 10;
+        const int a = axis[i], b = (a + 1) % 3, c = (a + 2) % 3;
+        if (!(lo[a] < hi[a])) return false;
+        if (!(n[a] != 0.0 && n[b] == 0.0 && n[c] == 0.0 && u[a] == 0.0 && v[a] == 0.0)) return false;
+        if (q[a] != (upper[i] ? hi[a] : lo[a])) return false;
+        // u along one of the two other axes, v along the other, and together they reach from corner to corner
+        const bool ub = u[b] != 0.0 && u[c] == 0.0 && v[c] != 0.0 && v[b] == 0.0;
+        const bool uc = u[c] != 0.0 && u[b] == 0.0 && v[b] != 0.0 && v[c] == 0.0;
+        if (!ub && !uc) return false;
+        for (int x : {b, c}) {
+            const double e0 = q[x], e1 = q[x] + u[x] + v[x];
+            if (std::min(e0, e1) != lo[x] || std::max(e0, e1) != hi[x]) return false;
+        }
+    }
+    return true;
+}
 inline bool collect(Ctx& c, uint32_t e, int parent, int depth) {
     if (depth > 40) return false;
     const rt_node& n = c.nodes[e];
@@ -229,6 +269,13 @@ inline bool build_wide_slots(const Ctx& c, const rt_node* nodes, uint32_t root, 
         out.base[a] = lo - 2.0 * out.step[a];
         if (!std::isfinite(out.step[a]) || !std::isfinite(out.base[a])) return false;
     }
+    for (int a = 0; a < 3; ++a) {
+        // prim_box widens by 1e-5 (1 + |coordinate|); onto the grid: less than one step, one more step either side, and
+        // wide_box's f32 arithmetic is good for that extra step (see wide_begin); half a step on top
+        const double reach = std::max(std::fabs(out.bounds[2 * a]), std::fabs(out.bounds[2 * a + 1]));
+        const double widen = std::isfinite(reach) ? 1e-5 * (1.0 + reach) / out.step[a] : 0.0;
+        out.slack[a] = (float)std::min(widen + 3.5, 1e30);
+    }
     const size_t total = (width - 1) / (RT_WIDE - 1);
     out.nodes.assign(32 * total, 0u);
     for (uint32_t k = 1; k <= K; ++k) {
@@ -276,7 +323,7 @@ inline bool build_wide_slots(const Ctx& c, const rt_node* nodes, uint32_t root, 
                     if (ctr[0][axis] / have[0] < ctr[1][axis] / have[1]) axis |= 4u;  // the first half is the LOWER one here
                 }
             }
-            uint32_t kind = 0, first = 0;
+            uint32_t kind = 0, first = 0, boxes = 0;
             unsigned long long counts = 0ull;
             if (k == 1) {  // the items: consecutive runs of one array of primitives, the used slots first
                 bool ended = false;
@@ -290,10 +337,11 @@ inline bool build_wide_slots(const Ctx& c, const rt_node* nodes, uint32_t root, 
                     if ((kc >> 24) != kind || f != next) return false;
                     next = f + cnt;
                     counts |= (unsigned long long)cnt << (8u * j);
+                    if (kind == RT_NODE_QUADS && cnt == 6u && is_reference_box(c.quads, f)) boxes |= 1u << j;
                 }
             }
             words[24] = first;
-            words[25] = kind | axis << 8;
+            words[25] = kind | axis << 8 | boxes << 16;
             words[26] = (uint32_t)counts;
             words[27] = (uint32_t)(counts >> 32);
         }
@@ -365,7 +413,10 @@ struct WLane {
     unsigned long long pending;  // bits 8k .. 8k + 7: children of the level-k node above the cursor still to be visited
     uint32_t rev;                // fast mode: bit k set = the level-k node's children are taken from 7 down to 0
     uint32_t slot, level;     // the node to look at next is (level, slot >> 3 level)
-    uint32_t k, kend, kind;   // run in progress; kind bit 9: the leaf's box has yet to narrow the interval (lambda = 0)
+    uint32_t k, kend, kind;   // run in progress; kind bit 9: the leaf's box has yet to narrow the interval (lambda = 0);
+                              // bit 10: the item is a box whose sides have yet to be chosen (wide_box_pairs); bit 11: the
+                              // chosen sides are being tested, bits 12..14 which pairs those are; bit 8 and bits 16..:
+                              // lane_skip_pairs' mask of the pairs still to test
     uint32_t item_first, item_kind;  // the items of the level-1 node above the cursor: first primitive, kind,
     unsigned long long item_counts;  // primitives per item (a byte each)
     uint32_t state;
@@ -418,7 +469,7 @@ RT_HD void wide_goto(WLane& ln, const DWide& W, uint32_t k, uint32_t j) {
     const uint32_t first = ln.item_first + (uint32_t)((below * 0x0101010101010101ull) >> 56);
     const uint32_t count = (uint32_t)(ln.item_counts >> (8u * j)) & 0xFFu;
     const bool item = k == 1u;
-    ln.kind = item ? ((ln.item_kind & 0xFFu) | (W.lambda == 0u ? 0x200u : 0u)) : ln.kind;
+    ln.kind = item ? ((ln.item_kind & 0xFFu) | (W.lambda == 0u ? 0x200u : 0u) | (((ln.item_kind >> (16u + j)) & 1u) != 0u ? 0x400u : 0u)) : ln.kind;
     ln.k = item ? first : ln.k;
     ln.kend = item ? first + count : ln.kend;
     ln.level = k - 1u;
@@ -552,8 +603,51 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, Tally* tally = nullptr) {
 struct WideKeepsAll {
     RT_HD void fetch_ray(WLane&) const {}      // cur.inv, tmin, tmax
     RT_HD void fetch_cursor(WLane&) const {}   // pending, rev, slot, level, item_*
+    RT_HD void fetch_grid(WLane&) const {}     // ax .. bz
     RT_HD void stash_cursor(const WLane&) const {}
 };
+// Which pairs of a box's six sides (create_box's order: z = max, x = max | z = min, x = min | y = max, y = min) are worth
+// testing first, for a lane that stands on such an item with its cursor and grid coefficients at hand.  The reference tests
+// all six and keeps the closest hit; a ray meets a box's surface where it enters -- the side of the last axis to be
+// entered -- or, when that lies before its interval, where it leaves: the side of the first axis to be left.  Those
+// axes are read off the item's box on the grid (child j of the level-1 node above the cursor), whose planes lie within
+// slack[a] grid steps outside the box's own: side (a, entering) is a candidate when a's plane can be the last entered and
+// that can be inside the interval, side (a, leaving) when a's plane can be the first left and the entry can be before the
+// interval -- or at the exit itself, for a ray that only touches a corner or an edge.  Anything not finite (a ray parallel to a pair of sides, an origin too far away for the grid) makes every
+// pair a candidate.  0: the box lies wholly beyond the interval.  The caller tests the other pairs as well when the chosen ones give no hit, so the choice cannot
+// lose a hit; it cannot change one either: a side that is not a candidate is separated from the entry (or exit) point by
+// more than the slack, far beyond what the rounding of a quad's own test can bridge.
+RT_HD uint32_t wide_box_pairs(const DWide& W, const WLane& ln) {
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(W.nodes + 8u * wide_node_index(W.K, 1u, ln.slot >> RT_WIDE_LOG)) + 3u * (ln.slot & 7u);
+    const uint32_t wx = words[0], wy = words[1], wz = words[2];
+    const float x0 = fmaf((float)(wx & 0xFFFFu), ln.ax, ln.bx), x1 = fmaf((float)(wx >> 16), ln.ax, ln.bx);
+    const float y0 = fmaf((float)(wy & 0xFFFFu), ln.ay, ln.by), y1 = fmaf((float)(wy >> 16), ln.ay, ln.by);
+    const float z0 = fmaf((float)(wz & 0xFFFFu), ln.az, ln.bz), z1 = fmaf((float)(wz >> 16), ln.az, ln.bz);
+    const float nx = fminf(x0, x1), fx = fmaxf(x0, x1), ny = fminf(y0, y1), fy = fmaxf(y0, y1), nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+    const float mx = W.slack[0] * fabsf(ln.ax), my = W.slack[1] * fabsf(ln.ay), mz = W.slack[2] * fabsf(ln.az);
+    const bool finite = fabsf(x0) + fabsf(x1) + fabsf(y0) + fabsf(y1) + fabsf(z0) + fabsf(z1) + mx + my + mz < 1e30f;
+    const float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
+    const float s = (float)ln.s, sm = fabsf(s) * 4.8e-7f;
+    const bool entry = fmaxf(fmaxf(nx + mx, ny + my), nz + mz) >= s - sm;  // the entry point may lie inside the interval
+    // ... or before it; or the ray may only graze the box, entering where it leaves (a corner, an edge): then the sides
+    // it leaves by are hit at the same parameter as those it enters by, and the reference's order decides between them
+    const bool leave = tn <= s + sm || tf - (mx + my + mz) <= tn + (mx + my + mz);
+    // pairs: 0 = {z max, x max}, 1 = {z min, x min}, 2 = {y max, y min}; a ray running up an axis enters by its min side
+    const uint32_t px_in = ln.cur.d.x > 0.0 ? 2u : 1u, pz_in = ln.cur.d.z > 0.0 ? 2u : 1u;
+    const uint32_t px_out = 3u - px_in, pz_out = 3u - pz_in;
+    uint32_t mask = 0u;
+    mask |= (entry && nx + mx >= tn) ? px_in : 0u;
+    mask |= (entry && nz + mz >= tn) ? pz_in : 0u;
+    mask |= (entry && ny + my >= tn) ? 4u : 0u;
+    mask |= (leave && fx - mx <= tf) ? px_out : 0u;
+    mask |= (leave && fz - mz <= tf) ? pz_out : 0u;
+    mask |= (leave && fy - my <= tf) ? 4u : 0u;
+    // Nothing at all when the box begins beyond the interval's end as it stands now (the node above looked at it with
+    // the end of that moment; closer hits in the items before this one may have shortened it since)
+    const float e = (float)ln.e, em = fabsf(e) * 4.8e-7f;
+    if (finite && tn > e + em) return 0u;
+    return (finite && mask != 0u) ? mask : 7u;
+}
 template <bool COUNT, class Away = WideKeepsAll, int ONLY = 0>
 RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tally, const Away& away = Away()) {
     if (ln.kind & 0x200u) {  // lambda = 0: the item is a whole leaf, whose box narrows the interval first
@@ -573,8 +667,27 @@ RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tal
         ln.s = ok ? s : ln.s; ln.e = ok ? e : ln.e;
         ln.k = ok ? ln.k : ln.kend;
     }
+    if constexpr (ONLY == 0 || ONLY == RT_NODE_QUADS) {
+        if ((ln.kind & 0x400u) != 0u && ln.k < ln.kend) {  // a box: the sides the ray can meet first, the others only if those are missed
+            away.fetch_cursor(ln);
+            away.fetch_grid(ln);
+            const uint32_t mask = wide_box_pairs(W, ln);
+            ln.kind = (ln.kind & 0x3FFu) | 0x100u | (mask != 0u ? 0x800u : 0u) | mask << 12;
+            lane_skip_pairs(ln, mask);  // (no pair at all: straight to the item's end)
+        }
+    }
     if (ln.k < ln.kend) lane_prim_tests<COUNT, ONLY>(S, ln, tally);
-    if (ln.k >= ln.kend) { away.fetch_cursor(ln); wide_ascend(ln, W); away.stash_cursor(ln); }
+    if (ln.k >= ln.kend) {
+        if constexpr (ONLY == 0 || ONLY == RT_NODE_QUADS) {
+            if ((ln.kind & 0x800u) != 0u) {
+                const uint32_t first = ln.kend - 6u, rest = ~(ln.kind >> 12) & 7u;
+                const bool hit_here = (ln.best.ref >> RT_REF_KIND_SHIFT) == RT_NODE_QUADS && (ln.best.ref & RT_REF_INDEX_MASK) - first < 6u;
+                ln.kind &= ~0x800u;
+                if (!hit_here && rest != 0u) { ln.k = first; lane_skip_pairs(ln, rest); return; }
+            }
+        }
+        away.fetch_cursor(ln); wide_ascend(ln, W); away.stash_cursor(ln);
+    }
 }
 
 }  // namespace rt

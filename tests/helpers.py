@@ -153,3 +153,58 @@ def assert_hits_equal(got, want, exact=True, what="", uv_exact=True):
             assert np.array_equal(got[k], want[k]), f"{what}: {k} not bit-identical (max abs diff {np.abs(got[k] - want[k]).max()})"
         else:
             np.testing.assert_allclose(got[k], want[k], rtol=1e-12, atol=1e-300, err_msg=f"{what}: {k}")
+
+
+BOX_FLOOR_SIDE = 1.25
+BOX_FLOOR_HEIGHTS = np.random.RandomState(21).uniform(0.5, 3.0, (9, 9))
+
+
+def box_floor_scene(b):
+    """A 9 x 9 floor of create_box lists of different heights that touch their neighbours (final_scene's ground in
+    small), under a BVH, and a sphere above it."""
+    side, heights = BOX_FLOOR_SIDE, BOX_FLOOR_HEIGHTS
+    m = b.mat_lambertian(b.tex_solid(0.5, 0.5, 0.5))
+    lst = b.list_new()
+    for i in range(9):
+        for j in range(9):
+            x, z = -5.0 + i * side, -5.0 + j * side
+            b.list_add(lst, b.slice(b.box((x, 0.0, z), (x + side, float(heights[i, j]), z + side), m)))
+    world = b.list_new()
+    b.list_add(world, b.bvh(lst))
+    b.list_add(world, b.sphere((0.0, 30.0, 0.0), 2.0, m))
+    b.set_world(b.slice(world))
+
+
+def box_floor_rays(n=4000, seed=22):
+    """Rays that look for trouble on box_floor_scene: aimed exactly at corners and at points on edges, along the axes
+    and the space diagonals, from inside boxes, from top faces and corners, from far away; some with their own intervals.
+    Returns o, d, tmin, tmax."""
+    side, heights = BOX_FLOOR_SIDE, BOX_FLOOR_HEIGHTS
+    rs = np.random.RandomState(seed)
+    corners = np.array([[-5.0 + i * side, float(rs.choice([0.0, heights[min(i, 8), min(j, 8)]])), -5.0 + j * side]
+                        for i in range(10) for j in range(10)])
+    o = np.column_stack([rs.uniform(-7, 7, n), rs.uniform(0.2, 6.0, n), rs.uniform(-7, 7, n)])
+    d = rs.normal(size=(n, 3))
+    k = np.arange(n)
+    aim = corners[rs.randint(0, len(corners), n)]
+    d[:800] = aim[:800] - o[:800]                                           # exactly at a corner
+    edge = aim[800:1400] + np.column_stack([rs.uniform(0, side, 600), np.zeros(600), np.zeros(600)])
+    d[800:1400] = edge - o[800:1400]                                        # at a point on an edge along x
+    ax = rs.randint(0, 3, 500)
+    d[1400:1900] = 0.0
+    d[k[1400:1900], ax] = rs.choice([-1.0, 1.0], 500)                       # along an axis
+    o[1400:1650] = aim[1400:1650] + 0.0                                     # ... from a corner itself
+    d[1900:2200] = rs.choice([-1.0, 1.0], (300, 3))                         # along a space diagonal
+    o[2200:2700, 1] = rs.uniform(0.01, 0.45, 500)                           # from inside a box (every box is taller than 0.5)
+    o[2200:2700, 0] = rs.uniform(-5, 6.25, 500)
+    o[2200:2700, 2] = rs.uniform(-5, 6.25, 500)
+    i_, j_ = rs.randint(0, 9, 300), rs.randint(0, 9, 300)
+    o[2700:3000] = np.column_stack([-5.0 + i_ * side + rs.uniform(0, side, 300), heights[i_, j_], -5.0 + j_ * side + rs.uniform(0, side, 300)])
+    d[2700:3000, 1] = np.abs(d[2700:3000, 1]) * rs.choice([1.0, 0.05], 300)  # leaving a top face, some nearly level
+    o[3000:3300] = rs.uniform(-1, 1, (300, 3)) * 900.0 + np.array([0.0, 1000.0, 0.0])
+    d[3000:3300] = corners[rs.randint(0, len(corners), 300)] - o[3000:3300]  # from far away at a corner
+    tmin = np.full(n, 0.001)
+    tmax = np.full(n, np.inf)
+    tmin[3300:] = rs.uniform(0.0, 4.0, n - 3300)
+    tmax[3300:] = tmin[3300:] + rs.uniform(0.0, 8.0, n - 3300)
+    return o, d, tmin, tmax

@@ -116,6 +116,7 @@ extern "C" int sim_intersect(const sim_scene* sc, uint64_t seed, const double* o
                     W.refbox = reinterpret_cast<const double2*>(wb.refbox.data());
                     for (int ax = 0; ax < 3; ++ax) { W.base[ax] = wb.base[ax]; W.step[ax] = wb.step[ax]; }
                     W.K = wb.K; W.lambda = wb.lambda; W.chain = wb.chain; W.fast = (uint32_t)use_fast;
+                    for (int ax = 0; ax < 3; ++ax) W.slack[ax] = wb.slack[ax];
                     WLane wl;
                     wide_begin(wl, S, W, w, tmin[i], tmax[i], b);
                     while (wl.state != RT_W_DONE) {

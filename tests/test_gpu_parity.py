@@ -469,3 +469,25 @@ def test_edge_cases_empty_inputs_and_limits(gpu_scenes):
     o = np.array([[0.0, 100.0, 100.0], [278.0, 278.0, -800.0], [555.0, 10.0, 10.0]])
     d = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
     assert_hits_equal(scene.intersect(o, d, 0.0, np.inf), os_.builder.intersect(o, d, 0.0, np.inf), exact=True, what="walls")
+
+
+def test_box_floor_corners_edges_and_ties_match_the_oracle():
+    """rt_intersect_batch on a floor of touching boxes under a BVH (the eight-wide walk, which of a box's six quads tests
+    the sides a ray can meet first and the others only if those are missed) for rays aimed at corners, at edges, along
+    axes and diagonals, from inside boxes and from far away: exact against the oracle, ties at shared corners included
+    (a later quad takes a tie: parallelogram.rs:101-103)."""
+    from raytracer_amd import HostBuilder
+    from oracle import oracle as orc
+    from helpers import box_floor_rays, box_floor_scene
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    box_floor_scene(hb)
+    box_floor_scene(ob)
+    o, d, tmin, tmax = box_floor_rays()
+    scene = hb.commit(0)
+    try:
+        got, want = scene.intersect(o, d, tmin, tmax), ob.intersect(o, d, tmin, tmax)
+        assert_hits_equal(got, want, exact=True, what="box floor")
+        ties = (want["t"] == 1.0) & (want["hit"] == 1)
+        assert ties.sum() > 100  # (many rays aimed at a corner or an edge reach it at exactly t = 1)
+    finally:
+        scene.close()

@@ -231,3 +231,37 @@ def test_wide_trees_of_many_shapes_and_sizes(count, kinds, seed):
     assert np.array_equal(fast["hit"], want["hit"])
     same = fast["prim"] == want["prim"]
     assert same.mean() > 0.995 and np.array_equal(fast["t"][same], want["t"][same])
+
+
+def test_box_sides_are_chosen_without_changing_any_hit():
+    """A BVH of create_box lists (floor boxes like final_scene's, touching their neighbours) walked through its wide
+    tree: of a box's six quads the walk tests the pair(s) holding the sides a ray can enter (or, from inside, leave) by,
+    and the others only if those give no hit.  Rays aimed exactly at corners and at points on edges, rays along the axes
+    and along face diagonals, origins inside boxes, on faces and on corners, origins far away: every hit equals the
+    oracle's bit for bit, and far fewer than six quads are tested per box visited."""
+    from oracle import oracle as orc
+    from raytracer_amd import HostBuilder
+
+    from helpers import box_floor_rays, box_floor_scene
+    hb, ob = HostBuilder(), orc.OracleBuilder()
+    box_floor_scene(hb)
+    box_floor_scene(ob)
+    sim = HostSim(hb)
+    o, d, tmin, tmax = box_floor_rays()
+    n = len(o)
+    rng3 = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.uint32)
+    want = ob.intersect(o, d, tmin, tmax, rng3)
+    L = _stretch_mode()
+    L.sim_set_walk_mode(3)
+    try:
+        got = sim.intersect(o, d, tmin, tmax, rng3)
+        assert L.sim_wide_stretches() == 1
+    finally:
+        L.sim_set_walk_mode(0)
+    assert 0.5 < want["hit"].mean() < 0.999
+    assert_hits_equal(got, want, exact=True, what="boxes")
+    # the entry-by-entry walk with its cull boxes (a ray that enters a leaf's box exactly where the closest hit so far
+    # lies -- every ray aimed at a shared corner -- must still be offered the later boxes there: a later quad takes the tie)
+    plain = sim.intersect(o, d, tmin, tmax, rng3)
+    assert_hits_equal(plain, want, exact=True, what="boxes, entry by entry")
+    assert got["counters"]["prim_tests"] < 0.2 * want["counters"]["prim_tests"]
