@@ -1237,15 +1237,32 @@ RT_HD void lane_prim_tests(const DScene& S, LaneT& ln, Tally& tally) {
         const bool is_tri = kind == RT_NODE_TRIANGLES;
         const double2* rec = reinterpret_cast<const double2*>(is_tri ? S.tris : S.quads) + 8u * ln.k;
         const Planar g0 = load_planar(rec);
-        const Planar g1 = load_planar(rec + (two ? 8u : 0u));
         if (COUNT) { tally.prim_tests += two ? 2u : 1u; tally.prim_bytes += two ? 272u : 136u; tally.prim_flops += two ? 120u : 60u; }
-        double t0, t1;
+        double t0, t1 = 0.0;
         // Triangles without branches (a mesh's rays fail each of a triangle's checks at different points, and a lane's
         // early exit saves the wavefront nothing); quads with them: on the sides of a box most lanes fail the first check,
         // the interval, together (measured: final_scene - 3 % of its walk with, bust - 21 % without).
-        const bool h0 = is_tri ? planar_flat_t(g0, true, ln.cur, ln.s, ln.e, t0) : planar_t(g0, false, ln.cur, ln.s, ln.e, t0);
+        bool h1 = false;
+        if (is_tri) {
+            // (a run of one -- every item of a mesh's wide tree -- reads and tests one record, not the same one twice)
+            const bool h0 = planar_flat_t(g0, true, ln.cur, ln.s, ln.e, t0);
+            ln.e = h0 ? t0 : ln.e;
+            if (two) {
+                const Planar g1 = load_planar(rec + 8u);
+                h1 = planar_flat_t(g1, true, ln.cur, ln.s, ln.e, t1);
+            }
+            ln.e = h1 ? t1 : ln.e;
+            ln.best.t = h1 ? t1 : (h0 ? t0 : ln.best.t);
+            ln.best.ref = h1 ? make_ref(kind, ln.k + 1u) : (h0 ? make_ref(kind, ln.k) : ln.best.ref);
+            ln.best.chain = (h0 | h1) ? ln.cur_chain : ln.best.chain;
+            ln.k = ln.k + (two ? 2u : 1u);
+            if (ln.kind & 0x100u) lane_skip_pairs(ln, (ln.kind >> 16) >> 1);
+            return;
+        }
+        const Planar g1 = load_planar(rec + (two ? 8u : 0u));
+        const bool h0 = planar_t(g0, false, ln.cur, ln.s, ln.e, t0);
         ln.e = h0 ? t0 : ln.e;  // (the second primitive is tested against the interval the first has left)
-        const bool h1 = two && (is_tri ? planar_flat_t(g1, true, ln.cur, ln.s, ln.e, t1) : planar_t(g1, false, ln.cur, ln.s, ln.e, t1));
+        h1 = two && planar_t(g1, false, ln.cur, ln.s, ln.e, t1);
         ln.e = h1 ? t1 : ln.e;
         ln.best.t = h1 ? t1 : (h0 ? t0 : ln.best.t);
         ln.best.ref = h1 ? make_ref(kind, ln.k + 1u) : (h0 ? make_ref(kind, ln.k) : ln.best.ref);
