@@ -17,10 +17,10 @@
 // boxes of its eight children on a 16-bit grid, rounded outwards (none of them narrows anything: a subtree is passed
 // over only when the ray's interval cannot touch the geometry below it).  A lane walks it with a cursor that only
 // moves forward, as the reference does, and remembers which children of the nodes above it are still to be visited
-// in eight bits per level of one 64-bit register.  The reference's narrowing by the leaf's own f64 box happens at the
-// level-1 nodes of the leaf (lambda = 1; every one of them does it: the narrowed interval is a function of the box and
-// of the closest hit so far, so doing it again gives what carrying it along would) or, where every leaf is a single
-// item and eight leaves share a level-1 node (lambda = 0), in the item's first primitive step.
+// in eight bits per level of one 64-bit register.  The reference's narrowing by the leaf's own f64 box happens in the
+// first primitive step below each level-1 node of the leaf (lambda = 1; below every one of them anew: the narrowed
+// interval is a function of the box and of the closest hit so far, so doing it again gives what carrying it along
+// would) or, where every leaf is a single item and eight leaves share a level-1 node (lambda = 0), in each item's.
 #pragma once
 
 #include "rt_core.h"
@@ -415,7 +415,8 @@ struct WLane {
     double s, e;              // inside a leaf: the interval its box narrowed that to, e shortened by every hit since
     Best best;
     unsigned long long pending;  // bits 8k .. 8k + 7: children of the level-k node above the cursor still to be visited
-    uint32_t rev;                // fast mode: bit k set = the level-k node's children are taken from 7 down to 0
+    uint32_t rev;                // fast mode: bit k set = the level-k node's children are taken from 7 down to 0;
+                                 // bit 31: the leaf's box has yet to narrow the interval below the level-1 node above (lambda = 1)
     uint32_t slot, level;     // the node to look at next is (level, slot >> 3 level)
     uint32_t k, kend, kind;   // run in progress; kind bit 9: the leaf's box has yet to narrow the interval (lambda = 0);
                               // bit 10: the item is a box whose sides have yet to be chosen (wide_box_pairs); bit 11: the
@@ -473,7 +474,7 @@ RT_HD void wide_goto(WLane& ln, const DWide& W, uint32_t k, uint32_t j) {
     const uint32_t first = ln.item_first + (uint32_t)((below * 0x0101010101010101ull) >> 56);
     const uint32_t count = (uint32_t)(ln.item_counts >> (8u * j)) & 0xFFu;
     const bool item = k == 1u;
-    ln.kind = item ? ((ln.item_kind & 0xFFu) | (W.lambda == 0u ? 0x200u : 0u) | (((ln.item_kind >> (16u + j)) & 1u) != 0u ? 0x400u : 0u)) : ln.kind;
+    ln.kind = item ? ((ln.item_kind & 0xFFu) | ((W.lambda == 0u || (ln.rev >> 31) != 0u) ? 0x200u : 0u) | (((ln.item_kind >> (16u + j)) & 1u) != 0u ? 0x400u : 0u)) : ln.kind;
     ln.k = item ? first : ln.k;
     ln.kend = item ? first + count : ln.kend;
     ln.level = k - 1u;
@@ -507,7 +508,7 @@ RT_HD void wide_ascend(WLane& ln, const DWide& W) {
     wide_goto(ln, W, k, j);
     ln.state = none ? RT_W_DONE : ln.state;
 }
-// One node for a lane in RT_W_NODE: the reference's narrowing when the node is a leaf's, then its eight child boxes.
+// One node for a lane in RT_W_NODE: its eight child boxes.
 struct WNodeRec { uint4 q0, q1, q2, q3, q4, q5, tail; };  // the first 112 bytes of a node
 RT_HD uint32_t wide_cursor_node(const DWide& W, const WLane& ln) { return wide_node_index(W.K, ln.level, ln.slot >> (RT_WIDE_LOG * ln.level)); }
 // `tally` (counting passes only): node_tests counts the reference's box test of a leaf, wide_tests the child boxes.
@@ -523,24 +524,12 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec, Tally*
         ln.item_kind = k == 1u ? tail.y : ln.item_kind;
         ln.item_counts = k == 1u ? ((unsigned long long)tail.w << 32 | tail.z) : ln.item_counts;
     }
-    bool missed = false;
-    if (W.lambda != 0u && k == W.lambda) {  // BVHNode::hit's box test for the leaf (bvh.rs:31-37)
-        const double2* rb = W.refbox + 3u * (ln.slot >> (RT_WIDE_LOG * W.lambda));
-        const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
-#if defined(__HIP_DEVICE_COMPILE__)
-        // keeps the compiler from sinking the loads into the slab test's branches, where each would wait on its own
-        asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x));
-#endif
-        double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
-        if (tally) tally->node_tests++;
-        // (no early exit: a leaf that is missed ends up with no child to visit, below)
-        const bool ok = slab3_flat(b0, b1, b2, ln.cur, s, e);
-        ln.s = ok ? s : ln.s; ln.e = ok ? e : ln.e;
-        missed = !ok;
-    }
+    // A leaf's node (lambda = 1) leaves BVHNode::hit's box test for the leaf (bvh.rs:31-37) to the first of its items
+    // the walk goes to (wide_prim_step): most rays that get here touch none of the items' boxes, and the test's three
+    // loads and f64 arithmetic would be paid by the whole wavefront in every step any lane stands on such a node.
+    ln.rev = (W.lambda != 0u && k == W.lambda) ? (ln.rev | 0x80000000u) : ln.rev;
     if (tally) tally->wide_tests += RT_WIDE;
-    const bool inside = k <= W.lambda;
-    const double ds = inside ? ln.s : ln.tmin, de = fmin(inside ? ln.e : ln.tmax, ln.best.t);
+    const double ds = ln.tmin, de = fmin(ln.tmax, ln.best.t);
     float cs = (float)ds, ce = (float)de;
     cs = fmaf(-fabsf(cs), 1.1920929e-7f, cs);  // not above ds, not below de (an infinity stays one)
     ce = fmaf(fabsf(ce), 1.1920929e-7f, ce);
@@ -558,7 +547,6 @@ RT_HD void wide_node_step(const DWide& W, WLane& ln, const WNodeRec& rec, Tally*
     RT_WIDE_CHILD(6u, q4.z, q4.w, q5.x)
     RT_WIDE_CHILD(7u, q5.y, q5.z, q5.w)
 #undef RT_WIDE_CHILD
-    m = missed ? 0u : m;
     if (!W.fast) {
         // The children to visit join those of the nodes above, and the walk goes on with the nearest of them all: the
         // lowest set bit is this node's first such child when it has one (no bit of a lower level is set while the
@@ -654,11 +642,11 @@ RT_HD uint32_t wide_box_pairs(const DWide& W, const WLane& ln) {
 }
 template <bool COUNT, class Away = WideKeepsAll, int ONLY = 0>
 RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tally, const Away& away = Away()) {
-    if (ln.kind & 0x200u) {  // lambda = 0: the item is a whole leaf, whose box narrows the interval first
-        ln.kind &= ~0x200u;
+    if (ln.kind & 0x200u) {  // the leaf's box narrows the interval first: the item is a whole leaf (lambda = 0), or the
+        ln.kind &= ~0x200u;  // first one the walk has come to below a leaf's node (lambda = 1)
         away.fetch_ray(ln);
         away.fetch_cursor(ln);
-        const double2* rb = W.refbox + 3u * ln.slot;
+        const double2* rb = W.refbox + 3u * (ln.slot >> (RT_WIDE_LOG * W.lambda));
         const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
 #if defined(__HIP_DEVICE_COMPILE__)
         // keeps the compiler from sinking the loads into the slab test's branches, where each would wait on its own
@@ -670,6 +658,12 @@ RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tal
         const bool ok = slab3_flat(b0, b1, b2, ln.cur, s, e);
         ln.s = ok ? s : ln.s; ln.e = ok ? e : ln.e;
         ln.k = ok ? ln.k : ln.kend;
+        if (W.lambda != 0u) {
+            // done for this node's other items too; a leaf that is missed has none of them visited
+            ln.rev &= 0x7FFFFFFFu;
+            ln.pending = ok ? ln.pending : (ln.pending & ~(0xFFull << 8));
+            away.stash_cursor(ln);
+        }
     }
     if constexpr (ONLY == 0 || ONLY == RT_NODE_QUADS) {
         if ((ln.kind & 0x400u) != 0u && ln.k < ln.kend) {  // a box: the sides the ray can meet first, the others only if those are missed
