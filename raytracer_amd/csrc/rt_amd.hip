@@ -68,11 +68,23 @@ struct Queue {
     uint32_t* ctr;                        // next draw index of the path's random stream
     uint32_t* sig;                        // ray_signature of the ray (written by k_raygen and k_bounce_lockstep only)
 };
+// Closest hit per queue slot, one 16-byte record each: t (f64), reference, chain -- written and read whole by one store /
+// load per lane (the walks' gathers and scattered stores are what this code pays for), t alone by an 8-byte one.
 struct HitBuf {
-    double* t;
-    uint32_t* ref;
-    uint32_t* chain;
+    uint4* rec;
 };
+__device__ __forceinline__ void hb_put(const HitBuf& hb, size_t i, double t, uint32_t ref, uint32_t chain) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+    uint4 v; v.x = (uint32_t)bits; v.y = (uint32_t)(bits >> 32); v.z = ref; v.w = chain;
+    hb.rec[i] = v;
+}
+__device__ __forceinline__ Best hb_get(const HitBuf& hb, size_t i) {
+    const uint4 v = hb.rec[i];
+    Best b; b.t = __longlong_as_double((long long)((unsigned long long)v.y << 32 | v.x)); b.ref = v.z; b.chain = v.w;
+    return b;
+}
+__device__ __forceinline__ double hb_t(const HitBuf& hb, size_t i) { return reinterpret_cast<const double*>(hb.rec)[2u * i]; }
+__device__ __forceinline__ void hb_set_t(const HitBuf& hb, size_t i, double t) { reinterpret_cast<double*>(hb.rec)[2u * i] = t; }
 
 extern __shared__ double2 g_levels[];
 
@@ -142,11 +154,11 @@ __global__ void __launch_bounds__(256) k_raygen(const SigInfo* __restrict__ Gp, 
         q.slot[idx] = slot0 + j;
         q.ctr[idx] = rng.ctr;
         if (Gp->n != 0u) q.sig[idx] = ray_signature(*Gp, o, d);
-        if (gates.n && gates.init_hits) { hb.t[idx] = RT_INF; hb.ref[idx] = RT_NO_HIT; }
+        if (gates.n && gates.init_hits) hb_put(hb, idx, RT_INF, RT_NO_HIT, 0u);
     }
     const uint32_t bits = gates_of(gates, alive, o, d);
     if (alive) q.born[idx] = iter | (gates.tag ? bits << RT_BORN_BITS : 0u);
-    if (gates.tag && bits != 0u) hb.t[idx] = RT_INF;
+    if (gates.tag && bits != 0u) hb_set_t(hb, idx, RT_INF);
     gates_append(gates, bits, idx, counts);
 }
 
@@ -235,7 +247,7 @@ struct TravArgs {
 };
 __device__ __forceinline__ Best trav_best_setup(const TravArgs& a, uint32_t idx) {
     Best b; b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
-    if (a.resume) { b.t = a.hb.t[idx]; b.ref = a.hb.ref[idx]; b.chain = a.hb.chain[idx]; }
+    if (a.resume) b = hb_get(a.hb, idx);
     return b;
 }
 __device__ __forceinline__ void trav_ray_setup(const TravArgs& a, uint32_t idx, RngPos& rng, double& tmin, double& tmax) {
@@ -273,7 +285,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
         src.ox = a.q.ox; src.oy = a.q.oy; src.oz = a.q.oz; src.dx = a.q.dx; src.dy = a.q.dy; src.dz = a.q.dz; src.idx = idx;
         Best b = closest_hit_range<COUNT, true, MEDIA>(S, src, tmin, tmax, L, rng, tally, first, first + (a.end - a.first),
                                                        trav_best_setup(a, idx));
-        a.hb.t[idx] = b.t; a.hb.ref[idx] = b.ref; a.hb.chain[idx] = b.chain;
+        hb_put(a.hb, idx, b.t, b.ref, b.chain);
         if (MEDIA != RT_MEDIA_NONE) a.q.ctr[idx] = rng.ctr;  // (only a medium draws during the walk)
     }
     if (COUNT) tally_flush(tally, tallies);
@@ -321,7 +333,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
         // wavefront its instructions however few lanes it serves
         if (mask != 0ull && (__popcll(mask) >= RT_FETCH_THRESHOLD || n_node + n_run + n_med + n_chain + n_sub == 0)) {
             if (need && idx != 0xFFFFFFFFu) {
-                a.hb.t[idx] = ln.best.t; a.hb.ref[idx] = ln.best.ref; a.hb.chain[idx] = ln.best.chain;
+                hb_put(a.hb, idx, ln.best.t, ln.best.ref, ln.best.chain);
                 a.q.ctr[idx] = rng.ctr;
                 idx = 0xFFFFFFFFu;
             }
@@ -491,7 +503,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
                             const Ray w = ray_world(mk(a.q.ox[idx], a.q.oy[idx], a.q.oz[idx]), mk(a.q.dx[idx], a.q.dy[idx], a.q.dz[idx]));
                             // going on from an earlier launch's closest hits: only t of that hit is read, and the
                             // hit is written back only if the tree holds a closer one (the buffer keeps what it has)
-                            Best b0; b0.t = carried ? a.hb.t[idx] : RT_INF; b0.ref = carried ? RT_REF_CARRIED : RT_NO_HIT; b0.chain = 0u;
+                            Best b0; b0.t = carried ? hb_t(a.hb, idx) : RT_INF; b0.ref = carried ? RT_REF_CARRIED : RT_NO_HIT; b0.chain = 0u;
                             wide_begin(ln, S, W, w, tmin, tmax, b0);
                             away.stash_all(ln);
                         }
@@ -501,7 +513,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
                 }
             }
             if (done_idx != 0xFFFFFFFFu && done_best.ref != RT_REF_CARRIED) {
-                a.hb.t[done_idx] = done_best.t; a.hb.ref[done_idx] = done_best.ref; a.hb.chain[done_idx] = done_best.chain;
+                hb_put(a.hb, done_idx, done_best.t, done_best.ref, done_best.chain);
             }
             if (exhausted && __ballot(ln.state != RT_W_DONE) == 0ull) break;
             n_node = __popcll(__ballot(ln.state == RT_W_NODE));
@@ -648,7 +660,7 @@ __global__ void k_finalize_batch(DScene S, Queue q, HitBuf hb, uint32_t n, uint8
                                  double* p3, double* n3, double* uv2, uint8_t* front, uint32_t* ctr_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Best b; b.t = hb.t[i]; b.ref = hb.ref[i]; b.chain = hb.chain[i];
+    Best b = hb_get(hb, i);
     bool h = b.ref != RT_NO_HIT;
     Rec rec;
     rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.u = 0; rec.v = 0; rec.front = false; rec.prim_id = RT_NO_HIT; rec.mat = 0;
@@ -798,8 +810,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
             born &= RT_BORN_MASK;
             w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
             if (reached != 0u) {
-                b.t = hb.t[idx];
-                if (b.t < RT_INF) { b.ref = hb.ref[idx]; b.chain = hb.chain[idx]; }  // (still infinity: no tree was hit)
+                b = hb_get(hb, idx);
+                if (!(b.t < RT_INF)) { b.ref = RT_NO_HIT; b.chain = 0u; }  // (still infinity: no tree was hit, the rest of the record is stale)
             }
             Best bw; bw.t = RT_INF; bw.ref = RT_NO_HIT; bw.chain = 0u;
             Tally unused = tally_zero();
@@ -810,7 +822,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
             const bool tree_wins = b.ref != RT_NO_HIT && b.t < bw.t;
             b.t = tree_wins ? b.t : bw.t; b.ref = tree_wins ? b.ref : bw.ref; b.chain = tree_wins ? b.chain : bw.chain;
         } else {
-            b.ref = hb.ref[idx];
+            b = hb_get(hb, idx);
         }
         if (b.ref == RT_NO_HIT) {
             lum_r[3u * (size_t)slot] = beta.x * bgr; lum_g[3u * (size_t)slot] = beta.y * bgg; lum_b[3u * (size_t)slot] = beta.z * bgb;
@@ -820,7 +832,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
             ctr = q.ctr[idx];
             if constexpr (!WALLS) {
                 w = ray_world(mk(q.ox[idx], q.oy[idx], q.oz[idx]), mk(q.dx[idx], q.dy[idx], q.dz[idx]));
-                b.t = hb.t[idx]; b.chain = hb.chain[idx];
             }
             rec = finalize<false, PLAIN>(S, w, b);
             m = S.mats[rec.mat];
@@ -898,12 +909,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PLAIN ? 6 : 4) k_shade(DScene S, 
         out.pix[dst] = pix; out.smp[dst] = smp; out.slot[dst] = slot;
         out.ctr[dst] = ctr;
         if (Gp->n != 0u) out.sig[dst] = sig;
-        if (gates.n && gates.init_hits) { hb_out.t[dst] = RT_INF; hb_out.ref[dst] = RT_NO_HIT; }
+        if (gates.n && gates.init_hits) hb_put(hb_out, dst, RT_INF, RT_NO_HIT, 0u);
     }
     // (the gate bits last: by now the new ray is all that is left in registers)
     const uint32_t bits = gates_of(gates, alive, no, nd);
     if (alive) out.born[dst] = born | (gates.tag ? bits << RT_BORN_BITS : 0u);
-    if (gates.tag && bits != 0u) hb_out.t[dst] = RT_INF;
+    if (gates.tag && bits != 0u) hb_set_t(hb_out, dst, RT_INF);
     gates_append(gates, bits, dst, out_count);
 }
 
@@ -1863,8 +1874,9 @@ static int rt_intersect_batch_impl(const rt_scene* s_, uint64_t seed, const doub
     }
     std::vector<void*> tmp;
     int rc = RT_OK;
-    double *d_soa, *d_tmin, *d_tmax, *d_t, *d_p, *d_n, *d_uv, *d_ht;
-    uint32_t *d_pix, *d_smp, *d_ctr, *d_prim, *d_cout, *d_href, *d_hchain;
+    double *d_soa, *d_tmin, *d_tmax, *d_t, *d_p, *d_n, *d_uv;
+    uint4* d_hits;
+    uint32_t *d_pix, *d_smp, *d_ctr, *d_prim, *d_cout;
     uint8_t *d_hit, *d_front;
     do {
         if ((rc = dev_copy_in(tmp, soa.data(), 6 * n, &d_soa))) break;
@@ -1873,9 +1885,7 @@ static int rt_intersect_batch_impl(const rt_scene* s_, uint64_t seed, const doub
         if ((rc = dev_copy_in(tmp, pix.data(), n, &d_pix))) break;
         if ((rc = dev_copy_in(tmp, smp.data(), n, &d_smp))) break;
         if ((rc = dev_copy_in(tmp, ctr.data(), n, &d_ctr))) break;
-        if ((rc = dev_alloc(tmp, true, n, &d_ht))) break;
-        if ((rc = dev_alloc(tmp, true, n, &d_href))) break;
-        if ((rc = dev_alloc(tmp, true, n, &d_hchain))) break;
+        if ((rc = dev_alloc(tmp, true, n, &d_hits))) break;
         if ((rc = dev_alloc(tmp, hit != nullptr, n, &d_hit))) break;
         if ((rc = dev_alloc(tmp, prim != nullptr, n, &d_prim))) break;
         if ((rc = dev_alloc(tmp, t != nullptr, n, &d_t))) break;
@@ -1889,7 +1899,7 @@ static int rt_intersect_batch_impl(const rt_scene* s_, uint64_t seed, const doub
         a.q.ox = d_soa; a.q.oy = d_soa + n; a.q.oz = d_soa + 2 * n;
         a.q.dx = d_soa + 3 * n; a.q.dy = d_soa + 4 * n; a.q.dz = d_soa + 5 * n;
         a.q.pix = d_pix; a.q.smp = d_smp; a.q.ctr = d_ctr;
-        a.hb.t = d_ht; a.hb.ref = d_href; a.hb.chain = d_hchain;
+        a.hb.rec = d_hits;
         a.seed = seed;
         a.segs.n = (uint32_t)n;
         a.segs.nclass = 1u;
@@ -1930,9 +1940,7 @@ static int rt_intersect_batch_noalloc_impl(const rt_scene* s_, uint64_t seed, co
     a.q.ox = const_cast<double*>(od6); a.q.oy = a.q.ox + n; a.q.oz = a.q.ox + 2 * (size_t)n;
     a.q.dx = a.q.ox + 3 * (size_t)n; a.q.dy = a.q.ox + 4 * (size_t)n; a.q.dz = a.q.ox + 5 * (size_t)n;
     a.q.pix = rng3; a.q.smp = rng3 + n; a.q.ctr = rng3 + 2 * (size_t)n;
-    a.hb.t = reinterpret_cast<double*>(base);
-    a.hb.ref = reinterpret_cast<uint32_t*>(base + 8 * (size_t)RT_NOALLOC_MAX_RAYS);
-    a.hb.chain = reinterpret_cast<uint32_t*>(base + 12 * (size_t)RT_NOALLOC_MAX_RAYS);
+    a.hb.rec = reinterpret_cast<uint4*>(base);
     uint32_t* const work = reinterpret_cast<uint32_t*>(base + 16 * (size_t)RT_NOALLOC_MAX_RAYS);
     a.seed = seed;
     a.segs.n = n;
@@ -1975,14 +1983,10 @@ static int ensure_workspace(rt_scene* s, size_t paths, size_t lum, size_t hits, 
         if ((rc = ws_queue(s, s->qb, paths))) return rc;
     }
     if (hits) {
-        HIP_TRY(rt_hip_malloc((void**)&s->hb.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb.t);
-        HIP_TRY(rt_hip_malloc((void**)&s->hb.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.ref);
-        HIP_TRY(rt_hip_malloc((void**)&s->hb.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb.chain);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb.rec, hits * sizeof(uint4))); s->ws_allocs.push_back(s->hb.rec);
     }
     if (lists) {  // work lists are in use: a hit buffer for the second queue too, and the lists (one queue's length each)
-        HIP_TRY(rt_hip_malloc((void**)&s->hb2.t, hits * sizeof(double))); s->ws_allocs.push_back(s->hb2.t);
-        HIP_TRY(rt_hip_malloc((void**)&s->hb2.ref, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.ref);
-        HIP_TRY(rt_hip_malloc((void**)&s->hb2.chain, hits * sizeof(uint32_t))); s->ws_allocs.push_back(s->hb2.chain);
+        HIP_TRY(rt_hip_malloc((void**)&s->hb2.rec, hits * sizeof(uint4))); s->ws_allocs.push_back(s->hb2.rec);
         HIP_TRY(rt_hip_malloc((void**)&s->wl, lists * paths * sizeof(uint32_t))); s->ws_allocs.push_back(s->wl);
     }
     // the radiance of path slot k is three consecutive doubles at 3 k: the three stores of a finished path touch one
