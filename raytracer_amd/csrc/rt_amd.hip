@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -432,6 +433,18 @@ struct WideAway {
         f[0][lane] = ln.ax; f[1][lane] = ln.ay; f[2][lane] = ln.az; f[3][lane] = ln.bx; f[4][lane] = ln.by; f[5][lane] = ln.bz;
     }
 };
+// The same for a walk that has the registers to keep all but the reciprocal direction (the triangle walk: 104 without,
+// 113 with): no LDS traffic in a node step at all (cornell_model's walk - 2 %).
+struct WideAwayInv {
+    double (*d)[64];      // [3]: 1 / d
+    uint32_t lane;
+    __device__ __forceinline__ void fetch_ray(WLane& ln) const { ln.cur.inv = mk(d[0][lane], d[1][lane], d[2][lane]); }
+    __device__ __forceinline__ void fetch_cursor(WLane&) const {}
+    __device__ __forceinline__ void stash_cursor(const WLane&) const {}
+    __device__ __forceinline__ void fetch_grid(WLane&) const {}
+    __device__ __forceinline__ void fetch_all(WLane&) const {}
+    __device__ __forceinline__ void stash_all(const WLane& ln) const { d[0][lane] = ln.cur.inv.x; d[1][lane] = ln.cur.inv.y; d[2][lane] = ln.cur.inv.z; }
+};
 #define RT_REF_CARRIED 0xFFFFFFFEu  // "the closest hit so far is the one the hit buffer already holds" (no such kind)
 // COUNT: also tallies the tests done (counting passes; the timed launches are the instantiation without it).
 // ONLY: the one kind of primitive the tree's items hold (its tests alone are compiled in), or 0 for any mix.
@@ -442,7 +455,11 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
     __shared__ float away_f[6][64];
     __shared__ double away_d[5][64];
     __shared__ uint32_t away_u[9][64];
-    WideAway away; away.f = away_f; away.d = away_d; away.u = away_u; away.lane = threadIdx.x & 63u;
+    using AwayT = typename std::conditional<ONLY == RT_NODE_TRIANGLES && !COUNT && !PROF, WideAwayInv, WideAway>::type;
+    AwayT away;
+    if constexpr (std::is_same<AwayT, WideAway>::value) { away.f = away_f; away.d = away_d; away.u = away_u; }
+    else away.d = away_d;
+    away.lane = threadIdx.x & 63u;
     unsigned long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = PROF ? clock64() : 0ull;
     Tally tally = tally_zero();
@@ -529,7 +546,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, COUNT ? 2 : 4) k_traverse_wide(DSc
         }
         if (do_prim) {
             const unsigned long long t0 = PROF ? clock64() : 0ull;
-            if (ln.state == RT_W_PRIM) wide_prim_step<COUNT, WideAway, ONLY>(S, W, ln, tally, away);
+            if (ln.state == RT_W_PRIM) wide_prim_step<COUNT, AwayT, ONLY>(S, W, ln, tally, away);
             if (PROF) { __builtin_amdgcn_s_waitcnt(0); pc[2] += clock64() - t0; pc[5]++; pc[8] += (unsigned long long)n_prim; }
         }
     }
