@@ -609,9 +609,10 @@ struct WideKeepsAll {
 // pair a candidate.  0: the box lies wholly beyond the interval.  The caller tests the other pairs as well when the chosen ones give no hit, so the choice cannot
 // lose a hit; it cannot change one either: a side that is not a candidate is separated from the entry (or exit) point by
 // more than the slack, far beyond what the rounding of a quad's own test can bridge.
-RT_HD uint32_t wide_box_pairs(const DWide& W, const WLane& ln) {
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(W.nodes + 8u * wide_node_index(W.K, 1u, ln.slot >> RT_WIDE_LOG)) + 3u * (ln.slot & 7u);
-    const uint32_t wx = words[0], wy = words[1], wz = words[2];
+RT_HD const uint32_t* wide_item_box(const DWide& W, const WLane& ln) {  // the item's box on the grid: three words, as wide_box takes them
+    return reinterpret_cast<const uint32_t*>(W.nodes + 8u * wide_node_index(W.K, 1u, ln.slot >> RT_WIDE_LOG)) + 3u * (ln.slot & 7u);
+}
+RT_HD uint32_t wide_box_pairs(const DWide& W, const WLane& ln, uint32_t wx, uint32_t wy, uint32_t wz) {
     const float x0 = fmaf((float)(wx & 0xFFFFu), ln.ax, ln.bx), x1 = fmaf((float)(wx >> 16), ln.ax, ln.bx);
     const float y0 = fmaf((float)(wy & 0xFFFFu), ln.ay, ln.by), y1 = fmaf((float)(wy >> 16), ln.ay, ln.by);
     const float z0 = fmaf((float)(wz & 0xFFFFu), ln.az, ln.bz), z1 = fmaf((float)(wz >> 16), ln.az, ln.bz);
@@ -642,34 +643,41 @@ RT_HD uint32_t wide_box_pairs(const DWide& W, const WLane& ln) {
 }
 template <bool COUNT, class Away = WideKeepsAll, int ONLY = 0>
 RT_HD void wide_prim_step(const DScene& S, const DWide& W, WLane& ln, Tally& tally, const Away& away = Away()) {
-    if (ln.kind & 0x200u) {  // the leaf's box narrows the interval first: the item is a whole leaf (lambda = 0), or the
-        ln.kind &= ~0x200u;  // first one the walk has come to below a leaf's node (lambda = 1)
-        away.fetch_ray(ln);
+    // What an item's first step may have to do before its primitives: the leaf's box narrows the interval (the item is a
+    // whole leaf, lambda = 0, or the first one the walk has come to below a leaf's node, lambda = 1), and a box has its
+    // sides chosen.  Both read a few words whose addresses the cursor gives: the loads go out together, ahead of either use.
+    const bool narrow = (ln.kind & 0x200u) != 0u;
+    const bool boxed = (ONLY == 0 || ONLY == RT_NODE_QUADS) && (ln.kind & 0x400u) != 0u;
+    if (narrow || boxed) {
         away.fetch_cursor(ln);
-        const double2* rb = W.refbox + 3u * (ln.slot >> (RT_WIDE_LOG * W.lambda));
-        const double2 b0 = rb[0], b1 = rb[1], b2 = rb[2];
+        double2 b0, b1, b2;
+        b0.x = b0.y = b1.x = b1.y = b2.x = b2.y = 0.0;
+        uint32_t wx = 0u, wy = 0u, wz = 0u;
+        if (narrow) { const double2* rb = W.refbox + 3u * (ln.slot >> (RT_WIDE_LOG * W.lambda)); b0 = rb[0]; b1 = rb[1]; b2 = rb[2]; }
+        if (boxed) { const uint32_t* words = wide_item_box(W, ln); wx = words[0]; wy = words[1]; wz = words[2]; }
 #if defined(__HIP_DEVICE_COMPILE__)
-        // keeps the compiler from sinking the loads into the slab test's branches, where each would wait on its own
-        asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x));
+        // (also keeps the compiler from sinking the loads into the slab test's branches, where each would wait on its own)
+        asm volatile("" ::"v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(wx), "v"(wy), "v"(wz));
 #endif
-        double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
-        if (COUNT) tally.node_tests++;
-        // (no early exit: a leaf that is missed has its run ended here and moves on with the lanes whose runs are over)
-        const bool ok = slab3_flat(b0, b1, b2, ln.cur, s, e);
-        ln.s = ok ? s : ln.s; ln.e = ok ? e : ln.e;
-        ln.k = ok ? ln.k : ln.kend;
-        if (W.lambda != 0u) {
-            // done for this node's other items too; a leaf that is missed has none of them visited
-            ln.rev &= 0x7FFFFFFFu;
-            ln.pending = ok ? ln.pending : (ln.pending & ~(0xFFull << 8));
-            away.stash_cursor(ln);
+        if (narrow) {
+            ln.kind &= ~0x200u;
+            away.fetch_ray(ln);
+            double s = ln.tmin, e = fmin(ln.tmax, ln.best.t);
+            if (COUNT) tally.node_tests++;
+            // (no early exit: a leaf that is missed has its run ended here and moves on with the lanes whose runs are over)
+            const bool ok = slab3_flat(b0, b1, b2, ln.cur, s, e);
+            ln.s = ok ? s : ln.s; ln.e = ok ? e : ln.e;
+            ln.k = ok ? ln.k : ln.kend;
+            if (W.lambda != 0u) {
+                // done for this node's other items too; a leaf that is missed has none of them visited
+                ln.rev &= 0x7FFFFFFFu;
+                ln.pending = ok ? ln.pending : (ln.pending & ~(0xFFull << 8));
+                away.stash_cursor(ln);
+            }
         }
-    }
-    if constexpr (ONLY == 0 || ONLY == RT_NODE_QUADS) {
-        if ((ln.kind & 0x400u) != 0u && ln.k < ln.kend) {  // a box: the sides the ray can meet first, the others only if those are missed
-            away.fetch_cursor(ln);
+        if (boxed && ln.k < ln.kend) {  // a box: the sides the ray can meet first, the others only if those are missed
             away.fetch_grid(ln);
-            const uint32_t mask = wide_box_pairs(W, ln);
+            const uint32_t mask = wide_box_pairs(W, ln, wx, wy, wz);
             ln.kind = (ln.kind & 0x3FFu) | 0x100u | (mask != 0u ? 0x800u : 0u) | mask << 12;
             lane_skip_pairs(ln, mask);  // (no pair at all: straight to the item's end)
         }
