@@ -1046,8 +1046,15 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
 // index after the last bounce of any path).
 #define RT_FINISH_MAX (1u << 17)      // rays in flight (upper bound) from which the tail is taken in one launch
 #define RT_FINISH_MAX_BVH (1u << 20)  // the same for trees with BVH entries
-template <bool LOCKSTEP, int MEDIA, bool PLAIN>
-__global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
+// LEAN (trees whose stretches are eight-wide trees of one kind of primitive, LEAN, and runs of quads at the top level, see
+// rt_scene::lean): only that kind's test and the quads' are compiled in, and the runs of quads are a loop every lane takes
+// together instead of the entry-by-entry walk -- the kernel then needs 150-180 registers instead of 256 and more, and a
+// third wavefront fits a SIMD (the kernel spends its time waiting for the records of the tree, one dependent load after
+// the other).  many_spheres, all of which is this launch, + 15 %; the tail of cornell_model - 1.4 ms.
+// wavefronts per SIMD (168 registers each at three; spheres with every material would spill a hundred of them there)
+#define RT_FINISH_WAVES(LEAN, PLAIN) (((LEAN) != 0 && ((PLAIN) || (LEAN) == RT_NODE_TRIANGLES)) ? 3 : 2)
+template <bool LOCKSTEP, int MEDIA, bool PLAIN, int LEAN = 0>
+__global__ void __launch_bounds__(BOUNCE_BLOCK, RT_FINISH_WAVES(LEAN, PLAIN)) k_finish(
     DScene S, uint64_t seed, Segs segs, Queue q, double* lum_r, double* lum_g, double* lum_b, double bgr, double bgg,
     double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters, const Stretch* stretches,
     uint32_t n_stretch, const DWide* wides, uint32_t fast, uint32_t* work, uint32_t born_mask) {
@@ -1107,7 +1114,37 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
             RngPos rp; rp.k0 = (uint32_t)seed; rp.k1 = (uint32_t)(seed >> 32); rp.pixel = pix; rp.sample = smp; rp.ctr = ctr;
             Best b;
             bool walked = false;
-            if constexpr (!LOCKSTEP) {
+            if constexpr (LEAN != 0) {
+                walked = true;
+                b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
+                for (uint32_t si = 0; si < n_stretch; ++si) {
+                    const Stretch st = stretches[si];
+                    if (st.kind == RT_STRETCH_WIDE) {
+                        DWide W = wides[st.wide];
+                        W.fast = fast;
+                        WLane wl;
+                        wide_begin(wl, S, W, w, 0.001, RT_INF, b);
+                        // Spheres: the kind of step more lanes wait for, both kinds when both are many (as in
+                        // k_traverse_wide; many_spheres - 5 % of the launch).  Triangles: both kinds every turn (an item is
+                        // one triangle, so a lane is back on a node after every primitive step, and a turn it sits out
+                        // is a turn lost: a large mesh + 15 % with the rule above).
+                        for (;;) {
+                            const int n_node = __popcll(__ballot(wl.state == RT_W_NODE));
+                            const int n_prim = __popcll(__ballot(wl.state == RT_W_PRIM));
+                            if (n_node + n_prim == 0) break;
+                            const bool each = LEAN != RT_NODE_SPHERES;
+                            if ((each || n_node >= RT_WIDE_STEP_THRESHOLD || n_node >= n_prim) && wl.state == RT_W_NODE) wide_node_step(W, wl);
+                            else if ((each || n_prim >= RT_WIDE_STEP_THRESHOLD || n_prim > n_node) && wl.state == RT_W_PRIM) wide_prim_step<false, WideKeepsAll, LEAN>(S, W, wl, tally);
+                        }
+                        b = wl.best;
+                    } else {
+                        for (uint32_t i = st.first; i < st.end; ++i) {  // (the same entries for every lane: scalar loads)
+                            const Node nu = load_node(S, i);
+                            run_prims<false, true>(S, RT_NODE_QUADS, nu.first, nu.count, 0u, w, 0.001, fmin(RT_INF, b.t), b, tally);
+                        }
+                    }
+                }
+            } else if constexpr (!LOCKSTEP) {
                 if (n_stretch != 0u) {
                     walked = true;
                     b.t = RT_INF; b.ref = RT_NO_HIT; b.chain = 0;
@@ -1129,7 +1166,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, 2) k_finish(
                     }
                 }
             }
-            if (!walked) b = closest_hit<false, LOCKSTEP, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally);
+            if constexpr (LEAN == 0) { if (!walked) b = closest_hit<false, LOCKSTEP, MEDIA>(S, src, 0.001, RT_INF, L, rp, tally); }
             ctr = rp.ctr;
             if (b.ref == RT_NO_HIT) {
                 lum = beta * mk(bgr, bgg, bgb);
@@ -1299,6 +1336,9 @@ struct rt_scene {
     // or spheres: a render then walks the trees first and tests the quads inside the shade kernel (k_shade's WALLS
     // form), which saves the launch that would read every ray for those few quads.
     bool walls = false;
+    // Every stretch of the top level is an eight-wide tree of this one kind of primitive (triangles or spheres) or a run
+    // of quads in the world's own frame, and there is no medium: the tail kernel has a form for that (k_finish's LEAN).
+    int lean = 0;
     GateInfo gate;                 // one gate per wide tree (the first RT_MAX_GATES of them): wide tree w has gate w
     const GateInfo* d_gate = nullptr;
     int media_mode = RT_MEDIA_NONE;  // RT_MEDIA_FLAT when every medium's boundary is plain primitives, else RT_MEDIA_ANY
@@ -1595,6 +1635,25 @@ static int validate(rt_scene* s) {
             if (ok) ok = s->wide[(size_t)st.wide].only == RT_NODE_TRIANGLES || s->wide[(size_t)st.wide].only == RT_NODE_SPHERES;
         }
         s->walls = ok;
+    }
+    s->lean = 0;
+    if (s->has_bvh && !s->stretches.empty()) {  // (a medium is neither kind of stretch)
+        int only = 0;
+        bool ok = true;
+        for (const Stretch& st : s->stretches) {
+            if (st.kind == RT_STRETCH_WIDE && st.wide >= 0) {
+                const int o = (int)s->wide[(size_t)st.wide].only;
+                ok = ok && (o == RT_NODE_TRIANGLES || o == RT_NODE_SPHERES) && (only == 0 || only == o);
+                only = o;
+            } else {
+                ok = ok && st.kind == RT_STRETCH_LOCKSTEP;
+                for (uint32_t i = st.first; i < st.end && ok; ++i) {
+                    const rt_node& n = s->nodes[i];
+                    ok = n.kind == RT_NODE_QUADS && n.level == 0 && n.chain == 0;
+                }
+            }
+        }
+        if (ok) s->lean = only;
     }
     return RT_OK;
 }
@@ -2267,7 +2326,13 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 const uint32_t fblock = levels_lds(s, BOUNCE_BLOCK) > 48u * 1024u ? 64u : (uint32_t)BOUNCE_BLOCK;
                 // no more workgroups than the device holds at once (two of 256 lanes per CU): the lanes take the rays
                 // from the queue as they get free
-                const uint32_t resident = s->n_cus * (fblock == 64u ? 8u : 2u);
+#if defined(RT_DEV_KNOBS)
+                static const bool no_lean = getenv("RT_FINISH_GENERIC") != nullptr;
+#else
+                const bool no_lean = false;
+#endif
+                const int lean = (lockstep || nocull || no_lean || fblock != (uint32_t)BOUNCE_BLOCK) ? 0 : s->lean;
+                const uint32_t resident = s->n_cus * (fblock == 64u ? 8u : 2u) * (uint32_t)RT_FINISH_WAVES(lean, s->plain) / 2u;
                 const uint32_t blocks = std::min((upper_in + fblock - 1) / fblock, resident);
                 HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));
                 HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, sm));  // the counter the rays are handed out with
@@ -2279,11 +2344,15 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                     (gates.tag ? RT_BORN_MASK : 0xFFFFFFFFu)
 #define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(fblock), \
                                             levels_lds(s, fblock), sm, FINISH_ARGS)
-                if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
+#define LEAN(P, K) hipLaunchKernelGGL((k_finish<false, RT_MEDIA_NONE, P, K>), dim3(blocks), dim3(fblock), levels_lds(s, fblock), sm, FINISH_ARGS)
+                if (lean == RT_NODE_TRIANGLES) { if (s->plain) LEAN(true, RT_NODE_TRIANGLES); else LEAN(false, RT_NODE_TRIANGLES); }
+                else if (lean == RT_NODE_SPHERES) { if (s->plain) LEAN(true, RT_NODE_SPHERES); else LEAN(false, RT_NODE_SPHERES); }
+                else if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
                 else if (!lockstep) { if (s->plain) FINISH(false, RT_MEDIA_ANY, true); else FINISH(false, RT_MEDIA_ANY, false); }
                 else if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(true, RT_MEDIA_NONE, true); else FINISH(true, RT_MEDIA_NONE, false); }
                 else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) FINISH(true, RT_MEDIA_FLAT, true); else FINISH(true, RT_MEDIA_FLAT, false); }
                 else { if (s->plain) FINISH(true, RT_MEDIA_ANY, true); else FINISH(true, RT_MEDIA_ANY, false); }
+#undef LEAN
 #undef FINISH
 #undef FINISH_ARGS
                 HIP_TRY(hipEventRecord(s->ev[2], sm));
