@@ -392,6 +392,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
 // an item.  The ray is taken into the tree's instance chain where it is handed out, by all lanes that take one
 // together; no random numbers are drawn here (no medium below such an entry).
 #define RT_WIDE_STEP_THRESHOLD 24
+#define RT_WIDE_RAYS_PER_LANE 24u  // of the queue, from which a launch has every wavefront the device holds
 #define RT_WIDE_FETCH_THRESHOLD 16
 // PROF: also adds up, per wavefront, the clock cycles spent handing out rays / in node steps / in primitive steps, the
 // number of each and the lanes that took part (development aid: RT_WIDE_PROF=1 prints the sums after a render).
@@ -1887,7 +1888,16 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
             const int tf = RT_WIDE_FETCH_THRESHOLD, ts = RT_WIDE_STEP_THRESHOLD;
             const bool prof = false;
 #endif
-            const uint32_t grid = std::min(waves, s->wide_waves / wdiv);
+#if defined(RT_DEV_KNOBS)
+            static const uint32_t per_lane = getenv("RT_WIDE_PER_LANE") ? (uint32_t)std::max(1, atoi(getenv("RT_WIDE_PER_LANE"))) : RT_WIDE_RAYS_PER_LANE;
+#else
+            const uint32_t per_lane = RT_WIDE_RAYS_PER_LANE;
+#endif
+            // A launch over few rays is as long as its longest walk, step after step, and a step takes the longer the more
+            // wavefronts share the SIMD: below RT_WIDE_RAYS_PER_LANE rays of the queue per lane the grid shrinks with the
+            // queue, down to one wavefront per SIMD (cornell_model at 8 spp, launches of 5 M rays and fewer: - 8 %).
+            const uint32_t wanted = std::max(s->wide_waves / 4u, n_upper / (TRAV_BLOCK * per_lane));
+            const uint32_t grid = std::min(waves, std::min(wanted, s->wide_waves / wdiv));
             a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
             a.thr_fetch = tf; a.thr_step = ts;
             DWide dw = s->d_wide[(size_t)st.wide];
