@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k_t
 // an item.  The ray is taken into the tree's instance chain where it is handed out, by all lanes that take one
 // together; no random numbers are drawn here (no medium below such an entry).
 #define RT_WIDE_STEP_THRESHOLD 24
-#define RT_WIDE_RAYS_PER_LANE 24u  // of the queue, from which a launch has every wavefront the device holds
+#define RT_WIDE_RAYS_PER_LANE 6u  // of a tree's list, from which its launch has every wavefront the device holds
 #define RT_WIDE_FETCH_THRESHOLD 16
 // PROF: also adds up, per wavefront, the clock cycles spent handing out rays / in node steps / in primitive steps, the
 // number of each and the lanes that took part (development aid: RT_WIDE_PROF=1 prints the sums after a render).
@@ -1859,7 +1859,7 @@ static int dev_alloc(std::vector<void*>& keep, bool want, size_t n, T** out) {
 // `n_upper`: no fewer rays than the launch will find (it sizes the grid; the kernels read the true numbers themselves).
 // k0: the first stretch to walk (1 when the quads of stretch 0 are left to the shade kernel, see rt_scene::walls)
 static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool nocull, uint32_t n_upper, uint32_t* work = nullptr,
-                           size_t k0 = 0) {
+                           size_t k0 = 0, const double* list_share = nullptr) {
     if (!work) work = s->d_count + 4;  // the counter the per-lane kernels hand rays out with
     DScene d = s->d;
     if (nocull) { d.nodes = s->nodes_nocull; d.n_variants = 1u; }
@@ -1894,9 +1894,12 @@ static int launch_traverse(rt_scene* s, const TravArgs& a_, bool count, bool noc
             const uint32_t per_lane = RT_WIDE_RAYS_PER_LANE;
 #endif
             // A launch over few rays is as long as its longest walk, step after step, and a step takes the longer the more
-            // wavefronts share the SIMD: below RT_WIDE_RAYS_PER_LANE rays of the queue per lane the grid shrinks with the
-            // queue, down to one wavefront per SIMD (cornell_model at 8 spp, launches of 5 M rays and fewer: - 8 %).
-            const uint32_t wanted = std::max(s->wide_waves / 4u, n_upper / (TRAV_BLOCK * per_lane));
+            // wavefronts share the SIMD: below RT_WIDE_RAYS_PER_LANE rays of the tree's list per lane (the list's share of the
+            // queue as the host last saw it, `list_share`) the grid shrinks with the queue, down to one wavefront per SIMD
+            // (cornell_model at 8 to 32 spp, launches of 20 M rays and fewer: - 5 %).
+            const double share = (list_share && a.wl) ? std::min(1.0, std::max(0.0, list_share[st.wide])) : 1.0;
+            const uint32_t listed = (uint32_t)((double)n_upper * share);
+            const uint32_t wanted = std::max(s->wide_waves / 4u, listed / (TRAV_BLOCK * per_lane));
             const uint32_t grid = std::min(waves, std::min(wanted, s->wide_waves / wdiv));
             a.chunk = std::max(64u, std::min(RT_CHUNK, (n_upper / std::max(1u, s->wide_waves) + 63u) / 64u * 64u));
             a.thr_fetch = tf; a.thr_step = ts;
@@ -2255,6 +2258,8 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
         Queue qin = s->qa, qout = s->qb;
         uint32_t injected = 0, accumulated = 0, consumed = 0, last_busy = 0;
         uint32_t known_out = 0;                // exact number of rays iteration `consumed - 1` left behind
+        double list_share[RT_MAX_GATES];       // of the rays an iteration left behind, the part in each tree's list (as last seen)
+        for (double& v : list_share) v = 1.0;
         bool finished = false;                 // the tail went to k_finish
         HIP_TRY(hipMemsetAsync(s->d_ring, 0, RT_RING_WORDS * 4, sm));  // nothing waits before iteration 0
         auto consume = [&]() -> int {          // read what iteration `consumed` left behind
@@ -2266,6 +2271,9 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
             known_out = 0;
             for (uint32_t c = 0; c < nclass; ++c) known_out += s->h_ring[rn * RT_RING_WORDS + RT_COUNT_STRIDE * c];
             if (two_shades && n_in >= 4096u && (uint64_t)s->h_ring[rn * RT_RING_WORDS + RT_DEFER_WORD] * 3u > n_in) two_shades = false;
+            if (gated && known_out >= 4096u)
+                for (uint32_t g = 0; g < s->gate.n; ++g)
+                    list_share[g] = (double)s->h_ring[rn * RT_RING_WORDS + RT_COUNT_STRIDE * (4u + g)] / (double)known_out;
             float ms = 0;
             if (bounce) {
                 HIP_TRY(hipEventElapsedTime(&ms, s->ring_ev[r][0], s->ring_ev[r][2]));
@@ -2403,7 +2411,7 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 }
                 ta.fast = (o->flags & RT_FLAG_FAST_BVH) ? 1u : 0u;
                 if (walls) ta.resume = 1u;  // (from t = infinity, written where the ray was made)
-                if ((rc = launch_traverse(s, ta, count, nocull, upper_in, nullptr, walls ? 1 : 0))) return rc;
+                if ((rc = launch_traverse(s, ta, count, nocull, upper_in, nullptr, walls ? 1 : 0, gated ? list_share : nullptr))) return rc;
                 HIP_TRY(hipEventRecord(s->ring_ev[r][1], sm));
                 const uint32_t sblocks = (upper_in + SHADE_BLOCK - 1) / SHADE_BLOCK + nclass + 1u;
 #define SHADE_ARGS s->d, s->d_sig, o->seed, segs, qin, hb_in, qout, out_count, s->lum_r, s->lum_g, s->lum_b, o->background[0], \
