@@ -1052,10 +1052,13 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, MEDIA == RT_MEDIA_ANY ? 3 : 4) k
 // together instead of the entry-by-entry walk -- the kernel then needs 150-180 registers instead of 256 and more, and a
 // third wavefront fits a SIMD (the kernel spends its time waiting for the records of the tree, one dependent load after
 // the other).  many_spheres, all of which is this launch, + 15 %; the tail of cornell_model - 1.4 ms.
-// wavefronts per SIMD (168 registers each at three; spheres with every material would spill a hundred of them there)
-#define RT_FINISH_WAVES(LEAN, PLAIN) (((LEAN) != 0 && ((PLAIN) || (LEAN) == RT_NODE_TRIANGLES)) ? 3 : 2)
-template <bool LOCKSTEP, int MEDIA, bool PLAIN, int LEAN = 0>
-__global__ void __launch_bounds__(BOUNCE_BLOCK, RT_FINISH_WAVES(LEAN, PLAIN)) k_finish(
+// LIGHT (with LEAN; scenes whose textures are solid colours and checkers of them, see rt_scene::light_tex): no perlin
+// arithmetic and no (u, v) -- only an image texture reads those, and a sphere's take an acos and an atan2 -- which
+// is what keeps spheres with every material at 252 registers (164 without).
+// wavefronts per SIMD (168 registers each at three; spheres with every material and texture would spill a hundred of them there)
+#define RT_FINISH_WAVES(LEAN, PLAIN, LIGHT) (((LEAN) != 0 && ((PLAIN) || (LIGHT) || (LEAN) == RT_NODE_TRIANGLES)) ? 3 : 2)
+template <bool LOCKSTEP, int MEDIA, bool PLAIN, int LEAN = 0, bool LIGHT = false>
+__global__ void __launch_bounds__(BOUNCE_BLOCK, RT_FINISH_WAVES(LEAN, PLAIN, LIGHT)) k_finish(
     DScene S, uint64_t seed, Segs segs, Queue q, double* lum_r, double* lum_g, double* lum_b, double bgr, double bgg,
     double bgb, uint32_t iter, uint32_t max_depth, unsigned long long* counters, const Stretch* stretches,
     uint32_t n_stretch, const DWide* wides, uint32_t fast, uint32_t* work, uint32_t born_mask) {
@@ -1173,7 +1176,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, RT_FINISH_WAVES(LEAN, PLAIN)) k_
                 lum = beta * mk(bgr, bgg, bgb);
                 ended = true;
             } else {
-                rec = finalize<false, PLAIN>(S, w, b);
+                rec = finalize<false, PLAIN || LIGHT>(S, w, b);
                 m = S.mats[rec.mat];
                 hit = true;
             }
@@ -1183,7 +1186,7 @@ __global__ void __launch_bounds__(BOUNCE_BLOCK, RT_FINISH_WAVES(LEAN, PLAIN)) k_
         if (hit) {
             Rng rng = rng_make(seed, pix, smp, ctr);
             V3 nd, att, emit;
-            if (!scatter_given<PLAIN>(S, m, d, rec, rng, ruv, nd, att, emit)) {
+            if (!scatter_given<PLAIN, !LIGHT>(S, m, d, rec, rng, ruv, nd, att, emit)) {
                 lum = beta * emit;
                 ended = true;
             } else if (it - born + 1u == max_depth) {
@@ -1340,6 +1343,7 @@ struct rt_scene {
     // Every stretch of the top level is an eight-wide tree of this one kind of primitive (triangles or spheres) or a run
     // of quads in the world's own frame, and there is no medium: the tail kernel has a form for that (k_finish's LEAN).
     int lean = 0;
+    bool light_tex = false;  // every texture is a solid colour or a checker (of such): nothing reads (u, v), no perlin noise
     GateInfo gate;                 // one gate per wide tree (the first RT_MAX_GATES of them): wide tree w has gate w
     const GateInfo* d_gate = nullptr;
     int media_mode = RT_MEDIA_NONE;  // RT_MEDIA_FLAT when every medium's boundary is plain primitives, else RT_MEDIA_ANY
@@ -1656,6 +1660,8 @@ static int validate(rt_scene* s) {
         }
         if (ok) s->lean = only;
     }
+    s->light_tex = true;
+    for (const rt_texture& t : s->texs) s->light_tex = s->light_tex && (t.kind == RT_TEX_SOLID || t.kind == RT_TEX_CHECKER);
     return RT_OK;
 }
 
@@ -2350,7 +2356,13 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
                 const bool no_lean = false;
 #endif
                 const int lean = (lockstep || nocull || no_lean || fblock != (uint32_t)BOUNCE_BLOCK) ? 0 : s->lean;
-                const uint32_t resident = s->n_cus * (fblock == 64u ? 8u : 2u) * (uint32_t)RT_FINISH_WAVES(lean, s->plain) / 2u;
+#if defined(RT_DEV_KNOBS)
+                static const bool no_light = getenv("RT_FINISH_NOLIGHT") != nullptr;
+#else
+                const bool no_light = false;
+#endif
+                const bool light_tex = s->light_tex && !no_light;
+                const uint32_t resident = s->n_cus * (fblock == 64u ? 8u : 2u) * (uint32_t)RT_FINISH_WAVES(lean, s->plain, light_tex) / 2u;
                 const uint32_t blocks = std::min((upper_in + fblock - 1) / fblock, resident);
                 HIP_TRY(hipMemsetAsync(s->d_count + 8, 0, 16, sm));
                 HIP_TRY(hipMemsetAsync(s->d_count + 4, 0, 4, sm));  // the counter the rays are handed out with
@@ -2363,13 +2375,15 @@ static int rt_render_device_impl(const rt_scene* s_, const rt_camera* cam, const
 #define FINISH(LS, M, P) hipLaunchKernelGGL((k_finish<LS, M, P>), dim3(blocks), dim3(fblock), \
                                             levels_lds(s, fblock), sm, FINISH_ARGS)
 #define LEAN(P, K) hipLaunchKernelGGL((k_finish<false, RT_MEDIA_NONE, P, K>), dim3(blocks), dim3(fblock), levels_lds(s, fblock), sm, FINISH_ARGS)
-                if (lean == RT_NODE_TRIANGLES) { if (s->plain) LEAN(true, RT_NODE_TRIANGLES); else LEAN(false, RT_NODE_TRIANGLES); }
-                else if (lean == RT_NODE_SPHERES) { if (s->plain) LEAN(true, RT_NODE_SPHERES); else LEAN(false, RT_NODE_SPHERES); }
+#define LEAN_LIGHT(K) hipLaunchKernelGGL((k_finish<false, RT_MEDIA_NONE, false, K, true>), dim3(blocks), dim3(fblock), levels_lds(s, fblock), sm, FINISH_ARGS)
+                if (lean == RT_NODE_TRIANGLES) { if (s->plain) LEAN(true, RT_NODE_TRIANGLES); else if (light_tex) LEAN_LIGHT(RT_NODE_TRIANGLES); else LEAN(false, RT_NODE_TRIANGLES); }
+                else if (lean == RT_NODE_SPHERES) { if (s->plain) LEAN(true, RT_NODE_SPHERES); else if (light_tex) LEAN_LIGHT(RT_NODE_SPHERES); else LEAN(false, RT_NODE_SPHERES); }
                 else if (!lockstep && s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(false, RT_MEDIA_NONE, true); else FINISH(false, RT_MEDIA_NONE, false); }
                 else if (!lockstep) { if (s->plain) FINISH(false, RT_MEDIA_ANY, true); else FINISH(false, RT_MEDIA_ANY, false); }
                 else if (s->media_mode == RT_MEDIA_NONE) { if (s->plain) FINISH(true, RT_MEDIA_NONE, true); else FINISH(true, RT_MEDIA_NONE, false); }
                 else if (s->media_mode == RT_MEDIA_FLAT) { if (s->plain) FINISH(true, RT_MEDIA_FLAT, true); else FINISH(true, RT_MEDIA_FLAT, false); }
                 else { if (s->plain) FINISH(true, RT_MEDIA_ANY, true); else FINISH(true, RT_MEDIA_ANY, false); }
+#undef LEAN_LIGHT
 #undef LEAN
 #undef FINISH
 #undef FINISH_ARGS
