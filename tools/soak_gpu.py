@@ -97,7 +97,8 @@ def batch_case(seed):
 
 
 def room(b, seed):
-    """Six quads and a light, then one or two BVHs of one kind of primitive each (or a mix), materials drawn per seed."""
+    """Six quads and a light, then one or two BVHs of one kind of primitive each (or a mix), materials drawn per seed; every fourth seed
+    with two constant media among the top-level entries."""
     rs = np.random.RandomState(2000 + seed)
     rng = SceneRng(900 + seed)
     plain_only = seed % 3 == 0
@@ -140,6 +141,13 @@ def room(b, seed):
         if tree == 1:
             node = b.translate(b.rotate_y(node, 15.0), (0.2, 0.0, -0.1))
         b.list_add(world, node)
+    if seed % 4 == 3:  # media: a ball of fog, and a rotated box of smoke as in cornell_smoke
+        ball = b.sphere((5.5, 2.0, 5.0), 1.2, b.mat_dielectric(1.5))
+        if seed % 8 == 3:
+            b.list_add(world, ball)
+        b.list_add(world, b.constant_medium(ball, 0.6, b.tex_solid(0.2, 0.4, 0.9)))
+        smoke = b.translate(b.rotate_y(b.slice(b.box((0.0, 0.0, 0.0), (1.5, 3.0, 1.5), white)), 18.0), (1.5, 0.0, 3.0))
+        b.list_add(world, b.constant_medium(smoke, 0.9, b.tex_solid(0.0, 0.0, 0.0)))
     if not walls_first:
         for q in walls:
             b.list_add(world, b.quad(*q))
